@@ -1,0 +1,106 @@
+"""ctypes binding of include/fluid_amd.h (libfluid_amd.so).
+
+There is no fallback: if the HIP library is missing or a call fails, this
+module raises.  Nothing here (or anywhere in this package) touches oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._build import LIB
+
+OK, E_INVALID, E_NOMEM, E_HIP, E_COMM = 0, 1, 2, 3, 4
+U, V, DENS, U_PREV, V_PREV, DENS_PREV, TMP0, TMP1, TMP2 = range(9)
+NFIELDS = 9
+JACOBI_STREAM, JACOBI_LDS, JACOBI_NAIVE = 0, 1, 2
+XCHG_HALO, XCHG_GATHER, XCHG_MAX = 0, 1, 2
+FIELD_NAMES = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev", "tmp0", "tmp1", "tmp2")
+
+
+class FluidError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libfluid_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("n", C.c_int), ("rank", C.c_int), ("nranks", C.c_int), ("halo", C.c_int),
+                ("jacobi_variant", C.c_int), ("stream", C.c_void_p), ("arena", C.c_void_p),
+                ("arena_bytes", C.c_size_t)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("jacobi_ms", C.c_double), ("sweeps", C.c_longlong), ("solves", C.c_longlong)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int,
+                          C.POINTER(C.c_float))
+
+_HOSTF = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_ctx = C.c_void_p
+_i, _f = C.c_int, C.c_float
+
+# name -> argtypes; every listed function returns int status.  This table is
+# also what tests/test_abi.py checks against include/fluid_amd.h.
+SIGNATURES = {
+    "step": [_i, _f, _f, _f, _HOSTF, _HOSTF, _HOSTF],
+    "step_src": [_i, _f, _f, _f, _i] + [_HOSTF] * 6,
+    "fluid_release_cached": [],
+    "fluid_coefficients": [_i, _f, _f, C.POINTER(_f), C.POINTER(_f)],
+    "fluid_layout": [_i, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_size_t)],
+    "fluid_create": [_i, C.POINTER(_ctx)],
+    "fluid_create_ex": [C.POINTER(Config), C.POINTER(_ctx)],
+    "fluid_destroy": [_ctx],
+    "fluid_synchronize": [_ctx],
+    "fluid_owned_rows": [_ctx, C.POINTER(_i), C.POINTER(_i)],
+    "fluid_field_ptr": [_ctx, _i, C.POINTER(C.c_void_p)],
+    "fluid_upload": [_ctx, _i, _HOSTF],
+    "fluid_download": [_ctx, _i, _HOSTF],
+    "fluid_upload_rows": [_ctx, _i, _HOSTF, _i, _i],
+    "fluid_download_rows": [_ctx, _i, _HOSTF, _i, _i],
+    "fluid_fill": [_ctx, _i, _f],
+    "fluid_step": [_ctx, _f, _f, _f, _i, _i, _i],
+    "fluid_vel_step": [_ctx, _f, _f, _i],
+    "fluid_dens_step": [_ctx, _f, _f, _i],
+    "fluid_op_set_bnd": [_ctx, _i, _i],
+    "fluid_op_add_source": [_ctx, _i, _i, _f],
+    "fluid_op_jacobi_sweep": [_ctx, _i, _i, _i, _i, _f, _f],
+    "fluid_op_diffuse": [_ctx, _i, _i, _i, _f, _f, _i],
+    "fluid_op_advect": [_ctx, _i, _i, _i, _i, _i, _f],
+    "fluid_op_divergence": [_ctx, _i, _i, _i, _i],
+    "fluid_op_subtract_gradient": [_ctx, _i, _i, _i],
+    "fluid_residual": [_ctx, _i, _i, _f, _f, C.POINTER(_f)],
+    "fluid_absmax_velocity": [_ctx, _i, _i, C.POINTER(_f)],
+    "fluid_set_jacobi_variant": [_ctx, _i],
+    "fluid_timing_enable": [_ctx, _i],
+    "fluid_timing_read": [_ctx, C.POINTER(Timing), _i],
+    "fluid_set_exchange": [_ctx, EXCHANGE_FN, C.c_void_p],
+}
+# symbols with a non-status return type
+OTHER_SYMBOLS = {"fluid_last_error": (C.c_char_p, []), "fluid_arena_bytes": (C.c_size_t, [_i])}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if libfluid_amd.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise ImportError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB)
+        L = C.CDLL(LIB)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = C.c_int, args
+        for name, (res, args) in OTHER_SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise FluidError(rc, lib().fluid_last_error().decode(errors="replace"))

@@ -1,0 +1,492 @@
+// fluid_kernels.hip -- hand-written gfx950 (CDNA4) kernels for the
+// Stable-Fluids step: boundary, sources, Jacobi sweep, advection, divergence,
+// pressure-gradient subtraction, plus two wavefront reductions.
+//
+// Arithmetic contract (bit parity with the reference's
+// project/sequential/FluidSequential.c): every expression keeps the reference's
+// operand order, division is true IEEE division, and this file is compiled with
+// -ffp-contract=off so no multiply-add is fused.
+//
+// Device field layout (see DESIGN.md "Data layout in HBM"): a field is W=n+2
+// rows of `pitch` floats; column c of a row sits at float index c+XOFF with
+// XOFF=63, so interior column 1 starts a 256-byte line and a wave's 64 float4
+// accesses cover whole 128-byte lines.  Pad floats (index <63 and >n+64) are
+// zero-initialised and never read as data.
+//
+// Every stencil kernel takes a global interior row range [row_lo,row_hi) so the
+// same code serves one GPU (1..n) and a row slab of a multi-GPU run, and every
+// kernel applies the reference's set_bnd (FluidSequential.c:62-75) itself: the
+// thread that produces an interior cell next to a wall also writes the ghost
+// cell(s) derived from it, so no separate boundary launch is needed.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fluid_kernels.h"
+
+namespace fluid {
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float flip_if(bool c, float v) { return c ? -v : v; }
+
+// value of lane-1 / lane+1 across the whole 64-wide wave (DPP wave shifts; one
+// VALU op each, no LDS).  Lane 0 / 63 receive `edge`.
+__device__ __forceinline__ float from_lane_below(float v, float edge)
+{
+    int r = __builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v),
+                                        0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    return __int_as_float(r);
+}
+__device__ __forceinline__ float from_lane_above(float v, float edge)
+{
+    int r = __builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v),
+                                        0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+    return __int_as_float(r);
+}
+
+// Ghost cells that derive from interior cell (j,i) holding `val`
+// (FluidSequential.c:65-74): across a vertical wall the ghost is -val when
+// b==1, across a horizontal wall -val when b==2, else a copy; a corner is
+// 0.5f*(horizontal neighbour + vertical neighbour), both of which are ghosts of
+// the same corner-most interior cell.  Handles n==1 (a cell on several walls).
+__device__ __forceinline__ void emit_ghosts(float* __restrict__ f, size_t pitch, int n, int b,
+                                                 int j, int i, float val)
+{
+    const bool nx = (b == 1), ny = (b == 2);
+    const bool left = (j == 1), right = (j == n), top = (i == 1), bot = (i == n);
+    if (!(left | right | top | bot)) return;
+    const float gx = flip_if(nx, val);
+    const float gy = flip_if(ny, val);
+    const float corner = 0.5f * (gy + gx);   // 0.5f*(x[horizontal nbr] + x[vertical nbr])
+    float* r0 = f + XOFF;
+    float* ri = f + (size_t)i * pitch + XOFF;
+    float* rn = f + (size_t)(n + 1) * pitch + XOFF;
+    if (left) ri[0] = gx;
+    if (right) ri[n + 1] = gx;
+    if (top) r0[j] = gy;
+    if (bot) rn[j] = gy;
+    if (top & left) r0[0] = corner;
+    if (top & right) r0[n + 1] = corner;
+    if (bot & left) rn[0] = corner;
+    if (bot & right) rn[n + 1] = corner;
+}
+
+// ---------------------------------------------------------------------------
+// a2  set_bnd as its own kernel (C-ABI operator + tests; the step itself uses
+// the fused form).  One thread per edge index k in 1..n; thread k==1 / k==n
+// also writes the corners from the values it just produced.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_set_bnd(float* __restrict__ f, int pitch, int n, int b)
+{
+    const int k = 1 + blockIdx.x * 256 + threadIdx.x;
+    if (k > n) return;
+    const size_t P = (size_t)pitch;
+    const bool nx = (b == 1), ny = (b == 2);
+    float* r0 = f + XOFF;
+    float* rk = f + (size_t)k * P + XOFF;
+    float* r1 = f + P + XOFF;
+    float* rN = f + (size_t)n * P + XOFF;
+    float* rn = f + (size_t)(n + 1) * P + XOFF;
+    const float gl = flip_if(nx, rk[1]);      // x[0,k]
+    const float gr = flip_if(nx, rk[n]);      // x[n+1,k]
+    const float gt = flip_if(ny, r1[k]);      // x[k,0]
+    const float gb = flip_if(ny, rN[k]);      // x[k,n+1]
+    rk[0] = gl;
+    rk[n + 1] = gr;
+    r0[k] = gt;
+    rn[k] = gb;
+    if (k == 1) {
+        r0[0] = 0.5f * (gt + gl);                            // x[1,0] + x[0,1]
+        rn[0] = 0.5f * (gb + flip_if(nx, rN[1]));            // x[1,n+1] + x[0,n]
+    }
+    if (k == n) {
+        r0[n + 1] = 0.5f * (gt + flip_if(nx, r1[n]));        // x[n,0] + x[n+1,1]
+        rn[n + 1] = 0.5f * (gb + gr);                        // x[n,n+1] + x[n+1,n]
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a3  add_source: x += dt*s on every cell of rows [row_lo,row_hi), ghosts
+// included (FluidSequential.c:78-82).  Streams whole padded rows as float4
+// (pads are 0 and stay 0).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_add_source(float* __restrict__ x, const float* __restrict__ s,
+                                                    int pitch, int row_lo, int row_hi, float dt)
+{
+    const int nvec = pitch >> 2;
+    const size_t total = (size_t)(row_hi - row_lo) * nvec;
+    float4* xv = reinterpret_cast<float4*>(x + (size_t)row_lo * pitch);
+    const float4* sv = reinterpret_cast<const float4*>(s + (size_t)row_lo * pitch);
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        float4 a = xv[t];
+        const float4 c = sv[t];
+        a.x = a.x + dt * c.x;
+        a.y = a.y + dt * c.y;
+        a.z = a.z + dt * c.z;
+        a.w = a.w + dt * c.w;
+        xv[t] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a4  Jacobi sweep, three variants.  All compute, for interior rows
+// [row_lo,row_hi) and columns 1..n,
+//     out = (x0 + alpha*(((L + R) + U) + D)) / beta     (FluidSequential.c:95-96)
+// and the ghosts of `out` that derive from those cells.
+// ---------------------------------------------------------------------------
+
+// (i) naive-global: one thread per cell, five global loads.
+__global__ __launch_bounds__(256) void k_jacobi_naive(const float* __restrict__ x, const float* __restrict__ x0,
+                                                      float* __restrict__ out, int pitch, int n, int row_lo,
+                                                      int row_hi, float alpha, float beta, int b)
+{
+    const int j = 1 + blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = row_lo + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (j > n || i >= row_hi) return;
+    const size_t P = (size_t)pitch;
+    const float* c = x + (size_t)i * P + XOFF + j;
+    float nb = c[-1] + c[1];
+    nb = nb + c[-(ptrdiff_t)P];
+    nb = nb + c[P];
+    const float val = (x0[(size_t)i * P + XOFF + j] + alpha * nb) / beta;
+    out[(size_t)i * P + XOFF + j] = val;
+    emit_ghosts(out, P, n, b, j, i, val);
+}
+
+// (ii) LDS-tiled: a (TY+2)x(TX+2) halo tile of x staged in LDS per workgroup
+// (TX=64, TY=16, 256 threads, each thread 4 rows of one column).  Tile corners
+// are not needed by a 5-point stencil and are not loaded.
+constexpr int LT_X = 64, LT_Y = 16;
+__global__ __launch_bounds__(256) void k_jacobi_lds(const float* __restrict__ x, const float* __restrict__ x0,
+                                                    float* __restrict__ out, int pitch, int n, int row_lo,
+                                                    int row_hi, float alpha, float beta, int b)
+{
+    __shared__ float tile[LT_Y + 2][LT_X + 2 + 1];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // ty in 0..3
+    const int j0 = 1 + blockIdx.x * LT_X, i0 = row_lo + blockIdx.y * LT_Y;
+    const int j = j0 + tx;
+    const size_t P = (size_t)pitch;
+    const int rows = min(LT_Y, row_hi - i0);
+    const int cols = min(LT_X, n - j0 + 1);
+    // body + top/bottom halo rows: rows i0-1 .. i0+rows, 64 columns each
+    for (int r = ty; r < rows + 2; r += 4)
+        if (tx < cols) tile[r][tx + 1] = x[(size_t)(i0 - 1 + r) * P + XOFF + j];
+    // left/right halo columns
+    if (threadIdx.x < 2 * LT_Y) {
+        const int r = threadIdx.x >> 1, side = threadIdx.x & 1;
+        if (r < rows) {
+            const int jj = side ? j0 + cols : j0 - 1;
+            tile[r + 1][side ? cols + 1 : 0] = x[(size_t)(i0 + r) * P + XOFF + jj];
+        }
+    }
+    __syncthreads();
+    if (tx >= cols) return;
+#pragma unroll
+    for (int k = 0; k < LT_Y / 4; ++k) {
+        const int r = ty + 4 * k;
+        if (r >= rows) break;
+        const int i = i0 + r;
+        float nb = tile[r + 1][tx] + tile[r + 1][tx + 2];
+        nb = nb + tile[r][tx + 1];
+        nb = nb + tile[r + 2][tx + 1];
+        const float val = (x0[(size_t)i * P + XOFF + j] + alpha * nb) / beta;
+        out[(size_t)i * P + XOFF + j] = val;
+        emit_ghosts(out, P, n, b, j, i, val);
+    }
+}
+
+// (iii) streaming: each lane owns one float4 (4 columns) and walks RB rows
+// with a three-row register window, so every x row is fetched once per strip
+// (+2 halo rows per RB); left/right neighbours come from the adjacent lanes by
+// DPP wave shift, and only the wave's two edge lanes issue an extra dword load.
+// 16 bytes per lane, 1 KiB per wave-instruction, 256-byte aligned.
+template <int RB>
+__global__ __launch_bounds__(256) void k_jacobi_stream(const float* __restrict__ x, const float* __restrict__ x0,
+                                                       float* __restrict__ out, int pitch, int n, int row_lo,
+                                                       int row_hi, float alpha, float beta, int b)
+{
+    const int lane = threadIdx.x & 63;
+    const int vec = blockIdx.x * 256 + threadIdx.x;     // float4 index along the row
+    const int nvec = (n + 3) >> 2;
+    const int i0 = row_lo + blockIdx.y * RB;
+    const int i1 = min(i0 + RB, row_hi);
+    const bool active = vec < nvec;
+    const int v = active ? vec : nvec - 1;              // clamp: inactive lanes load valid memory
+    const int j = 1 + 4 * v;                            // first column of this lane
+    const size_t P = (size_t)pitch;
+    const float* xc = x + XOFF + j;
+    const float* rc = x0 + XOFF + j;
+    float* oc = out + XOFF + j;
+    const bool edge_lo = (lane == 0), edge_hi = (lane == 63) | (vec >= nvec - 1);
+    const bool nx = (b == 1), ny = (b == 2);
+
+    float4 up = *reinterpret_cast<const float4*>(xc + (size_t)(i0 - 1) * P);
+    float4 me = *reinterpret_cast<const float4*>(xc + (size_t)i0 * P);
+    for (int i = i0; i < i1; ++i) {
+        const float4 dn = *reinterpret_cast<const float4*>(xc + (size_t)(i + 1) * P);
+        const float4 r = *reinterpret_cast<const float4*>(rc + (size_t)i * P);
+        float le = 0.f, re = 0.f;
+        if (edge_lo) le = xc[(size_t)i * P - 1];
+        if (edge_hi) re = xc[(size_t)i * P + 4];
+        float L = from_lane_below(me.w, le);
+        float R = from_lane_above(me.x, re);
+        if (edge_lo) L = le;
+        if (edge_hi) R = re;
+        float4 o;
+        float nb;
+        nb = L + me.y;     nb = nb + up.x; nb = nb + dn.x; o.x = (r.x + alpha * nb) / beta;
+        nb = me.x + me.z;  nb = nb + up.y; nb = nb + dn.y; o.y = (r.y + alpha * nb) / beta;
+        nb = me.y + me.w;  nb = nb + up.z; nb = nb + dn.z; o.z = (r.z + alpha * nb) / beta;
+        nb = me.z + R;     nb = nb + up.w; nb = nb + dn.w; o.w = (r.w + alpha * nb) / beta;
+        if (active) {
+            float* orow = oc + (size_t)i * P;
+            const int last = n - j;            // component index of column n (>=0)
+            if (last >= 3) {
+                *reinterpret_cast<float4*>(orow) = o;
+            } else {                           // ragged right end: columns j..n only
+                orow[0] = o.x;
+                if (last >= 1) orow[1] = o.y;
+                if (last >= 2) orow[2] = o.z;
+            }
+            // ---- fused set_bnd (selects only: no runtime-indexed arrays) ----
+            const float vn = last == 0 ? o.x : last == 1 ? o.y : last == 2 ? o.z : o.w;  // column n
+            if (j == 1) orow[-1] = flip_if(nx, o.x);                       // x[0,i]
+            if (last <= 3) orow[last + 1] = flip_if(nx, vn);               // x[n+1,i]
+            if (i == 1 || i == n) {
+                float4 g4;
+                g4.x = flip_if(ny, o.x); g4.y = flip_if(ny, o.y);
+                g4.z = flip_if(ny, o.z); g4.w = flip_if(ny, o.w);
+                const float cl = 0.5f * (g4.x + flip_if(nx, o.x));          // corner next to column 1
+                const float cr = 0.5f * (flip_if(ny, vn) + flip_if(nx, vn)); // corner next to column n
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    if (side == 0 ? i != 1 : i != n) continue;
+                    float* g = oc + (side == 0 ? (size_t)0 : (size_t)(n + 1) * P);
+                    if (last >= 3) {
+                        *reinterpret_cast<float4*>(g) = g4;
+                    } else {
+                        g[0] = g4.x;
+                        if (last >= 1) g[1] = g4.y;
+                        if (last >= 2) g[2] = g4.z;
+                    }
+                    if (j == 1) g[-1] = cl;
+                    if (last <= 3) g[last + 1] = cr;
+                }
+            }
+        }
+        up = me;
+        me = dn;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// a5  advect (FluidSequential.c:107-141): one thread per cell; the wave reads
+// 64 consecutive u,v (coalesced) and gathers the four bilinear taps of d0.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_advect(float* __restrict__ d, const float* __restrict__ d0,
+                                                const float* __restrict__ u, const float* __restrict__ v,
+                                                int pitch, int n, int row_lo, int row_hi, float dt0, int b)
+{
+    const int j = 1 + blockIdx.x * 256 + threadIdx.x;
+    const int i = row_lo + blockIdx.y;
+    if (j > n || i >= row_hi) return;
+    const size_t P = (size_t)pitch;
+    const size_t c = (size_t)i * P + XOFF + j;
+    float px = (float)j - dt0 * u[c];
+    float py = (float)i - dt0 * v[c];
+    const float hi = (float)n + 0.5f;
+    if (px < 0.5f) px = 0.5f;
+    if (px > hi) px = hi;
+    if (py < 0.5f) py = 0.5f;
+    if (py > hi) py = hi;
+    const int j0 = (int)px, i0 = (int)py;
+    const float s1 = px - (float)j0, s0 = 1.0f - s1;
+    const float t1 = py - (float)i0, t0 = 1.0f - t1;
+    const float* q = d0 + (size_t)i0 * P + XOFF + j0;
+    const float a = t0 * q[0] + t1 * q[P];
+    const float e = t0 * q[1] + t1 * q[P + 1];
+    const float val = s0 * a + s1 * e;
+    d[c] = val;
+    emit_ghosts(d, P, n, b, j, i, val);
+}
+
+// ---------------------------------------------------------------------------
+// a6  divergence + pressure clear (FluidSequential.c:143-158).
+// div = (-0.5f*h) * (((uR - uL) + vD) - vU), p = 0, set_bnd(0) on both: the
+// ghosts of p are 0 as well, so p is zeroed on whole rows incl. ghost rows.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_divergence(const float* __restrict__ u, const float* __restrict__ v,
+                                                    float* __restrict__ p, float* __restrict__ div, int pitch,
+                                                    int n, int row_lo, int row_hi, float h)
+{
+    const int j = 1 + blockIdx.x * 256 + threadIdx.x;
+    const int i = row_lo + blockIdx.y;
+    if (j > n || i >= row_hi) return;
+    const size_t P = (size_t)pitch;
+    const size_t c = (size_t)i * P + XOFF + j;
+    const float scale = -0.5f * h;
+    float g = u[c + 1] - u[c - 1];
+    g = g + v[c + P];
+    g = g - v[c - P];
+    const float val = scale * g;
+    div[c] = val;
+    emit_ghosts(div, P, n, 0, j, i, val);
+    p[c] = 0.0f;
+    emit_ghosts(p, P, n, 0, j, i, 0.0f);
+}
+
+// ---------------------------------------------------------------------------
+// a7  pressure-gradient subtraction (FluidSequential.c:161-173):
+// u -= (0.5f*(pR-pL))/h ; v -= (0.5f*(pD-pU))/h ; set_bnd(1,u), set_bnd(2,v).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_subtract_gradient(float* __restrict__ u, float* __restrict__ v,
+                                                           const float* __restrict__ p, int pitch, int n,
+                                                           int row_lo, int row_hi, float h)
+{
+    const int j = 1 + blockIdx.x * 256 + threadIdx.x;
+    const int i = row_lo + blockIdx.y;
+    if (j > n || i >= row_hi) return;
+    const size_t P = (size_t)pitch;
+    const size_t c = (size_t)i * P + XOFF + j;
+    const float gx = 0.5f * (p[c + 1] - p[c - 1]);
+    const float gy = 0.5f * (p[c + P] - p[c - P]);
+    const float nu = u[c] - gx / h;
+    const float nv = v[c] - gy / h;
+    u[c] = nu;
+    v[c] = nv;
+    emit_ghosts(u, P, n, 1, j, i, nu);
+    emit_ghosts(v, P, n, 2, j, i, nv);
+}
+
+// ---------------------------------------------------------------------------
+// wavefront reductions (diagnostics + the advect halo bound of the slab path).
+// 64-lane __shfl_xor butterflies, one atomic per wave.  Neither feeds back
+// into the fields, so they cannot change results.
+//   k_absmax2 : max(|u|,|v|) over interior cells of rows [row_lo,row_hi)
+//               (non-negative floats order like their bit patterns => atomicMax
+//               on the uint view is exact and order independent).
+//   k_residual: max |beta*x - alpha*(L+R+U+D) - x0| over the same cells.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float m)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_absmax2(const float* __restrict__ u, const float* __restrict__ v,
+                                                 int pitch, int n, int row_lo, int row_hi,
+                                                 unsigned int* __restrict__ result)
+{
+    const size_t P = (size_t)pitch;
+    float m = 0.0f;
+    for (int i = row_lo + blockIdx.y; i < row_hi; i += gridDim.y)
+        for (int j = 1 + blockIdx.x * 256 + threadIdx.x; j <= n; j += gridDim.x * 256) {
+            const size_t c = (size_t)i * P + XOFF + j;
+            m = fmaxf(m, fmaxf(fabsf(u[c]), fabsf(v[c])));
+        }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(result, __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void k_residual(const float* __restrict__ x, const float* __restrict__ x0,
+                                                  int pitch, int n, int row_lo, int row_hi, float alpha,
+                                                  float beta, unsigned int* __restrict__ result)
+{
+    const size_t P = (size_t)pitch;
+    float m = 0.0f;
+    for (int i = row_lo + blockIdx.y; i < row_hi; i += gridDim.y)
+        for (int j = 1 + blockIdx.x * 256 + threadIdx.x; j <= n; j += gridDim.x * 256) {
+            const size_t c = (size_t)i * P + XOFF + j;
+            const float nb = x[c - 1] + x[c + 1] + x[c - P] + x[c + P];
+            m = fmaxf(m, fabsf(beta * x[c] - alpha * nb - x0[c]));
+        }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(result, __float_as_uint(m));
+}
+
+// ---------------------------------------------------------------------------
+// launch wrappers (host).  Shapes are validated by the caller (fluid_solver).
+// ---------------------------------------------------------------------------
+static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+void launch_set_bnd(hipStream_t s, float* f, int pitch, int n, int b)
+{
+    hipLaunchKernelGGL(k_set_bnd, dim3(cdiv(n, 256)), dim3(256), 0, s, f, pitch, n, b);
+}
+
+void launch_add_source(hipStream_t s, float* x, const float* src, int pitch, int row_lo, int row_hi, float dt)
+{
+    const size_t total = (size_t)(row_hi - row_lo) * (pitch >> 2);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_add_source, dim3(blocks ? blocks : 1), dim3(256), 0, s, x, src, pitch, row_lo, row_hi, dt);
+}
+
+void launch_jacobi(hipStream_t s, int variant, const float* x, const float* x0, float* out, int pitch, int n,
+                   int row_lo, int row_hi, float alpha, float beta, int b)
+{
+    const int rows = row_hi - row_lo;
+    if (rows <= 0) return;
+    switch (variant) {
+    case JACOBI_NAIVE:
+        hipLaunchKernelGGL(k_jacobi_naive, dim3(cdiv(n, 64), cdiv(rows, 4)), dim3(256), 0, s, x, x0, out, pitch, n,
+                           row_lo, row_hi, alpha, beta, b);
+        break;
+    case JACOBI_LDS:
+        hipLaunchKernelGGL(k_jacobi_lds, dim3(cdiv(n, LT_X), cdiv(rows, LT_Y)), dim3(256), 0, s, x, x0, out, pitch,
+                           n, row_lo, row_hi, alpha, beta, b);
+        break;
+    default: {
+        constexpr int RB = 8;
+        const unsigned nvec = (n + 3) / 4;
+        hipLaunchKernelGGL(k_jacobi_stream<RB>, dim3(cdiv(nvec, 256), cdiv(rows, RB)), dim3(256), 0, s, x, x0, out,
+                           pitch, n, row_lo, row_hi, alpha, beta, b);
+    }
+    }
+}
+
+void launch_advect(hipStream_t s, float* d, const float* d0, const float* u, const float* v, int pitch, int n,
+                   int row_lo, int row_hi, float dt0, int b)
+{
+    if (row_hi <= row_lo) return;
+    hipLaunchKernelGGL(k_advect, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s, d, d0, u, v, pitch, n, row_lo,
+                       row_hi, dt0, b);
+}
+
+void launch_divergence(hipStream_t s, const float* u, const float* v, float* p, float* div, int pitch, int n,
+                       int row_lo, int row_hi, float h)
+{
+    if (row_hi <= row_lo) return;
+    hipLaunchKernelGGL(k_divergence, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s, u, v, p, div, pitch, n,
+                       row_lo, row_hi, h);
+}
+
+void launch_subtract_gradient(hipStream_t s, float* u, float* v, const float* p, int pitch, int n, int row_lo,
+                              int row_hi, float h)
+{
+    if (row_hi <= row_lo) return;
+    hipLaunchKernelGGL(k_subtract_gradient, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s, u, v, p, pitch, n,
+                       row_lo, row_hi, h);
+}
+
+void launch_absmax2(hipStream_t s, const float* u, const float* v, int pitch, int n, int row_lo, int row_hi,
+                    unsigned int* result)
+{
+    if (row_hi <= row_lo) return;
+    const unsigned gy = (unsigned)(row_hi - row_lo) < 512u ? (unsigned)(row_hi - row_lo) : 512u;
+    const unsigned gx = cdiv(n, 256) < 8u ? cdiv(n, 256) : 8u;
+    hipLaunchKernelGGL(k_absmax2, dim3(gx, gy), dim3(256), 0, s, u, v, pitch, n, row_lo, row_hi, result);
+}
+
+void launch_residual(hipStream_t s, const float* x, const float* x0, int pitch, int n, int row_lo, int row_hi,
+                     float alpha, float beta, unsigned int* result)
+{
+    if (row_hi <= row_lo) return;
+    const unsigned gy = (unsigned)(row_hi - row_lo) < 512u ? (unsigned)(row_hi - row_lo) : 512u;
+    const unsigned gx = cdiv(n, 256) < 8u ? cdiv(n, 256) : 8u;
+    hipLaunchKernelGGL(k_residual, dim3(gx, gy), dim3(256), 0, s, x, x0, pitch, n, row_lo, row_hi, alpha, beta,
+                       result);
+}
+
+}  // namespace fluid

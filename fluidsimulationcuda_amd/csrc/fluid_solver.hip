@@ -1,0 +1,714 @@
+// fluid_solver.hip -- C++ host orchestrator + the extern "C" shim of
+// include/fluid_amd.h.  Owns device memory, sequences the kernels of
+// fluid_kernels.hip exactly as the reference's vel_step / dens_step do
+// (project/sequential/FluidSequential.c:176-241), and drives the row-slab halo
+// exchange through a callback when the grid is split over several GPUs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fluid_amd.h"
+#include "fluid_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? FLUID_E_NOMEM : FLUID_E_HIP, "%s: %s",   \
+                        #expr, hipGetErrorString(e_));                                       \
+    } while (0)
+
+#define TRY(expr)                        \
+    do {                                 \
+        int rc_ = (expr);                \
+        if (rc_ != FLUID_OK) return rc_; \
+    } while (0)
+
+constexpr int kMaxN = 1 << 20;   // index arithmetic is size_t; advect's clamp constant needs N < 2^23
+
+}  // namespace
+
+struct fluid_ctx {
+    int n = 0, w = 0, pitch = 0;
+    size_t field_floats = 0;
+    float* arena = nullptr;
+    bool own_arena = false;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    float* f[FLUID_NFIELDS] = {};
+    unsigned int* d_scalar = nullptr;     // device word for the reductions
+    unsigned int* h_scalar = nullptr;     // pinned host mirror
+    int variant = fluid::JACOBI_STREAM;
+    // slab decomposition
+    int rank = 0, nranks = 1, own0 = 1, own1 = 1, min_slab = 0, halo = 1;
+    fluid_exchange_fn xchg = nullptr;
+    void* xchg_user = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double jacobi_ms = 0.0;
+    long long sweeps = 0, solves = 0, pending_sweeps = 0;
+
+    bool valid_field(int id) const { return id >= 0 && id < FLUID_NFIELDS; }
+    int lo_all() const { return own0 - (rank == 0 ? 1 : 0); }          // owned rows incl. ghost row
+    int hi_all() const { return own1 + (rank == nranks - 1 ? 1 : 0); }
+};
+
+namespace {
+
+using fluid::XOFF;
+
+int check_ctx(const fluid_ctx* c)
+{
+    if (!c) return fail(FLUID_E_INVALID, "null context");
+    return FLUID_OK;
+}
+
+int check_fields(const fluid_ctx* c, std::initializer_list<int> ids)
+{
+    for (int id : ids)
+        if (!c->valid_field(id)) return fail(FLUID_E_INVALID, "bad field id %d", id);
+    return FLUID_OK;
+}
+
+int exchange(fluid_ctx* c, int kind, std::initializer_list<int> fields, int depth, float* scalar = nullptr)
+{
+    if (c->nranks == 1) return FLUID_OK;
+    if (!c->xchg) return fail(FLUID_E_COMM, "multi-GPU context without an exchange callback");
+    std::vector<int> ids(fields);
+    // the same field listed twice (self-advection) is exchanged once
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    const int rc = c->xchg(c->xchg_user, kind, ids.data(), (int)ids.size(), depth, scalar);
+    if (rc != 0) return fail(FLUID_E_COMM, "exchange callback failed (kind %d, rc %d)", kind, rc);
+    return FLUID_OK;
+}
+
+int reduce_to_host(fluid_ctx* c, float* out)
+{
+    HIP_TRY(hipMemcpyAsync(c->h_scalar, c->d_scalar, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float v;
+    std::memcpy(&v, c->h_scalar, sizeof v);
+    *out = v;
+    return FLUID_OK;
+}
+
+// ---- timing ---------------------------------------------------------------
+int timing_begin(fluid_ctx* c, hipEvent_t* stop_out)
+{
+    *stop_out = nullptr;
+    if (!c->timing) return FLUID_OK;
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        c->ev_pool.emplace_back(a, b);
+    }
+    auto& p = c->ev_pool[c->ev_used++];
+    HIP_TRY(hipEventRecord(p.first, c->stream));
+    *stop_out = p.second;
+    return FLUID_OK;
+}
+
+int timing_end(fluid_ctx* c, hipEvent_t stop, int sweeps)
+{
+    if (!stop) return FLUID_OK;
+    HIP_TRY(hipEventRecord(stop, c->stream));
+    c->pending_sweeps += sweeps;
+    return FLUID_OK;
+}
+
+int timing_collect(fluid_ctx* c)
+{
+    if (c->ev_used == 0) return FLUID_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < c->ev_used; ++k) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k].first, c->ev_pool[k].second));
+        c->jacobi_ms += ms;
+    }
+    c->solves += (long long)c->ev_used;
+    c->sweeps += c->pending_sweeps;
+    c->pending_sweeps = 0;
+    c->ev_used = 0;
+    return FLUID_OK;
+}
+
+// ---- operators on the owned slab -----------------------------------------------
+int op_add_source(fluid_ctx* c, int x, int s, float dt)
+{
+    fluid::launch_add_source(c->stream, c->f[x], c->f[s], c->pitch, c->lo_all(), c->hi_all(), dt);
+    return FLUID_OK;
+}
+
+// FluidSequential.c:85-104.  Result lands in field x (iters even).  With
+// several slabs the ghost zone is `halo` rows deep: one exchange, then `halo`
+// sweeps over a range that shrinks by one row per sweep on each inner edge --
+// the same arithmetic per cell as the 1-GPU run, so results are bit-identical.
+int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int iters)
+{
+    if (iters < 0 || (iters & 1)) return fail(FLUID_E_INVALID, "sweep count must be even and >= 0 (got %d)", iters);
+    if (x == x0 || x == FLUID_TMP0 || x0 == FLUID_TMP0)
+        return fail(FLUID_E_INVALID, "diffuse: x, x0 and TMP0 must be distinct fields");
+    if (iters == 0) return FLUID_OK;
+    hipEvent_t stop;
+    TRY(timing_begin(c, &stop));
+    float* cur = c->f[x];
+    float* nxt = c->f[FLUID_TMP0];
+    int cur_id = x, nxt_id = FLUID_TMP0;
+    const int H = c->nranks > 1 ? c->halo : 1;
+    if (c->nranks > 1) TRY(exchange(c, FLUID_XCHG_HALO, {x, x0}, H));
+    for (int k = 0; k < iters; ++k) {
+        const int s = k % H;
+        if (c->nranks > 1 && s == 0 && k > 0) TRY(exchange(c, FLUID_XCHG_HALO, {cur_id}, H));
+        const int reach = H - 1 - s;
+        const int lo = std::max(1, c->own0 - reach), hi = std::min(c->n + 1, c->own1 + reach);
+        fluid::launch_jacobi(c->stream, c->variant, cur, c->f[x0], nxt, c->pitch, c->n, lo, hi, alpha, beta, b);
+        std::swap(cur, nxt);
+        std::swap(cur_id, nxt_id);
+    }
+    HIP_TRY(hipGetLastError());
+    return timing_end(c, stop, iters);
+}
+
+// FluidSequential.c:107-141.  The back-trace reaches dt0*max|vel| cells, so a
+// slab first learns the global bound (wavefront reduction + MAX exchange) and
+// pulls that many rows of the advected field(s) from its neighbours; when the
+// reach exceeds the neighbours' slabs it falls back to gathering whole fields.
+int advect_prepare(fluid_ctx* c, std::initializer_list<int> sources, int u, int v, float dt0)
+{
+    if (c->nranks == 1) return FLUID_OK;
+    HIP_TRY(hipMemsetAsync(c->d_scalar, 0, sizeof(unsigned), c->stream));
+    fluid::launch_absmax2(c->stream, c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, c->d_scalar);
+    float vmax = 0.f;
+    TRY(reduce_to_host(c, &vmax));
+    TRY(exchange(c, FLUID_XCHG_MAX, {}, 0, &vmax));
+    const double reach = std::ceil((double)std::fabs(dt0) * (double)vmax) + 2.0;
+    if (!(reach <= (double)(c->min_slab - 1)))     // also catches NaN/inf
+        return exchange(c, FLUID_XCHG_GATHER, sources, 0);
+    return exchange(c, FLUID_XCHG_HALO, sources, (int)reach);
+}
+
+int op_advect(fluid_ctx* c, int b, int d, int d0, int u, int v, float dt)
+{
+    if (d == d0 || d == u || d == v) return fail(FLUID_E_INVALID, "advect: output must not alias an input");
+    const float dt0 = dt * (float)c->n;
+    fluid::launch_advect(c->stream, c->f[d], c->f[d0], c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, dt0, b);
+    return FLUID_OK;
+}
+
+int op_divergence(fluid_ctx* c, int u, int v, int p, int div)
+{
+    if (p == u || p == v || div == u || div == v || p == div)
+        return fail(FLUID_E_INVALID, "divergence: outputs must not alias inputs");
+    const float h = 1.0f / (float)c->n;
+    // ghost rows of p are zeroed together with the slab's edge rows by the fused boundary
+    fluid::launch_divergence(c->stream, c->f[u], c->f[v], c->f[p], c->f[div], c->pitch, c->n, c->own0, c->own1, h);
+    return FLUID_OK;
+}
+
+int op_subtract_gradient(fluid_ctx* c, int u, int v, int p)
+{
+    if (p == u || p == v || u == v) return fail(FLUID_E_INVALID, "subtract_gradient: fields must be distinct");
+    const float h = 1.0f / (float)c->n;
+    fluid::launch_subtract_gradient(c->stream, c->f[u], c->f[v], c->f[p], c->pitch, c->n, c->own0, c->own1, h);
+    return FLUID_OK;
+}
+
+void coefficients(int n, float dt, float coef, float* alpha, float* beta)
+{
+    // ((dt*coef)*n)*n in float, then 1 + 4*alpha (FluidSequential.c:179-180,199-200)
+    volatile float a = dt * coef;
+    a = a * (float)n;
+    a = a * (float)n;
+    volatile float four_a = 4.0f * a;
+    *alpha = a;
+    *beta = 1.0f + four_a;
+}
+
+// divergence -> 40-sweep pressure solve -> gradient subtraction
+// (FluidSequential.c:213-223 and :238-240)
+int project(fluid_ctx* c, int u, int v, int p, int div, int iters)
+{
+    TRY(exchange(c, FLUID_XCHG_HALO, {u, v}, 1));
+    TRY(op_divergence(c, u, v, p, div));
+    TRY(op_diffuse(c, 0, p, div, 1.0f, 4.0f, iters));
+    TRY(exchange(c, FLUID_XCHG_HALO, {p}, 1));
+    return op_subtract_gradient(c, u, v, p);
+}
+
+// FluidSequential.c:189-241 with the SWAPs resolved into field roles:
+// after :201/:209 the diffused velocity lives in the *_prev buffers.
+int vel_step(fluid_ctx* c, float dt, float visc, int iters)
+{
+    const int U = FLUID_U, V = FLUID_V, U0 = FLUID_U_PREV, V0 = FLUID_V_PREV;
+    float alpha, beta;
+    TRY(op_add_source(c, U, U0, dt));
+    TRY(op_add_source(c, V, V0, dt));
+    coefficients(c->n, dt, visc, &alpha, &beta);
+    TRY(op_diffuse(c, 1, U0, U, alpha, beta, iters));
+    TRY(op_diffuse(c, 2, V0, V, alpha, beta, iters));
+    TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
+    const float dt0 = dt * (float)c->n;
+    TRY(advect_prepare(c, {U0, V0}, U0, V0, dt0));
+    TRY(op_advect(c, 1, U, U0, U0, V0, dt));
+    TRY(op_advect(c, 2, V, V0, U0, V0, dt));
+    return project(c, U, V, /*p=*/U0, /*div=*/V0, iters);
+}
+
+// FluidSequential.c:176-186
+int dens_step(fluid_ctx* c, float dt, float diff, int iters)
+{
+    const int X = FLUID_DENS, X0 = FLUID_DENS_PREV;
+    float alpha, beta;
+    TRY(op_add_source(c, X, X0, dt));
+    coefficients(c->n, dt, diff, &alpha, &beta);
+    TRY(op_diffuse(c, 0, X0, X, alpha, beta, iters));
+    TRY(advect_prepare(c, {X0}, FLUID_U, FLUID_V, dt * (float)c->n));
+    return op_advect(c, 0, X, X0, FLUID_U, FLUID_V, dt);
+}
+
+int zero_sources(fluid_ctx* c)
+{
+    for (int id : {FLUID_U_PREV, FLUID_V_PREV, FLUID_DENS_PREV})
+        HIP_TRY(hipMemsetAsync(c->f[id], 0, c->field_floats * sizeof(float), c->stream));
+    return FLUID_OK;
+}
+
+int copy_rows(fluid_ctx* c, int field, float* host, const float* chost, int row_lo, int row_hi, bool to_device)
+{
+    if (row_lo < 0 || row_hi > c->w || row_lo > row_hi) return fail(FLUID_E_INVALID, "bad row range");
+    if (row_lo == row_hi) return FLUID_OK;
+    float* dev = c->f[field] + (size_t)row_lo * c->pitch + XOFF;
+    const size_t hp = (size_t)c->w * sizeof(float), dp = (size_t)c->pitch * sizeof(float);
+    const size_t rows = (size_t)(row_hi - row_lo);
+    if (to_device)
+        HIP_TRY(hipMemcpy2DAsync(dev, dp, chost + (size_t)row_lo * c->w, hp, hp, rows, hipMemcpyHostToDevice, c->stream));
+    else
+        HIP_TRY(hipMemcpy2DAsync(host + (size_t)row_lo * c->w, hp, dev, dp, hp, rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FLUID_OK;
+}
+
+thread_local fluid_ctx* g_cached = nullptr;
+
+}  // namespace
+
+// ===========================================================================
+// extern "C" shim
+// ===========================================================================
+extern "C" {
+
+const char* fluid_last_error(void) { return g_err.c_str(); }
+
+int fluid_coefficients(int N, float dt, float coef, float* alpha, float* beta)
+{
+    if (N < 1 || !alpha || !beta) return fail(FLUID_E_INVALID, "fluid_coefficients: bad argument");
+    coefficients(N, dt, coef, alpha, beta);
+    return FLUID_OK;
+}
+
+int fluid_layout(int N, int* pitch, int* xoff, size_t* field_floats)
+{
+    if (N < 1 || N > kMaxN) return fail(FLUID_E_INVALID, "N must be in [1, %d] (got %d)", kMaxN, N);
+    const int p = fluid::pitch_for(N);
+    if (pitch) *pitch = p;
+    if (xoff) *xoff = XOFF;
+    if (field_floats) *field_floats = (size_t)(N + 2) * p;
+    return FLUID_OK;
+}
+
+size_t fluid_arena_bytes(int N)
+{
+    size_t ff = 0;
+    if (fluid_layout(N, nullptr, nullptr, &ff) != FLUID_OK) return 0;
+    return ff * FLUID_NFIELDS * sizeof(float);
+}
+
+int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
+{
+    if (!cfg || !out) return fail(FLUID_E_INVALID, "fluid_create_ex: null argument");
+    *out = nullptr;
+    const int n = cfg->n;
+    if (n < 1 || n > kMaxN) return fail(FLUID_E_INVALID, "N must be in [1, %d] (got %d)", kMaxN, n);
+    const int P = cfg->nranks < 1 ? 1 : cfg->nranks;
+    if (cfg->rank < 0 || cfg->rank >= P) return fail(FLUID_E_INVALID, "rank %d outside [0,%d)", cfg->rank, P);
+    if (cfg->jacobi_variant < 0 || cfg->jacobi_variant >= fluid::JACOBI_VARIANTS)
+        return fail(FLUID_E_INVALID, "unknown Jacobi variant %d", cfg->jacobi_variant);
+    if (P > 1 && n / P < 2) return fail(FLUID_E_INVALID, "N=%d is too small for %d row slabs (need >= 2 rows each)", n, P);
+    fluid_ctx* c = new (std::nothrow) fluid_ctx;
+    if (!c) return fail(FLUID_E_NOMEM, "out of host memory");
+    c->n = n;
+    c->w = n + 2;
+    c->pitch = fluid::pitch_for(n);
+    c->field_floats = (size_t)c->w * c->pitch;
+    c->variant = cfg->jacobi_variant;
+    c->rank = cfg->rank;
+    c->nranks = P;
+    const int base = n / P, rem = n % P;
+    c->own0 = 1 + cfg->rank * base + std::min(cfg->rank, rem);
+    c->own1 = c->own0 + base + (cfg->rank < rem ? 1 : 0);
+    c->min_slab = base;
+    // ghost-zone depth: never reaches a neighbour's wall rows (depth <= slab-1)
+    const int want = cfg->halo > 0 ? cfg->halo : 8;
+    c->halo = P > 1 ? std::max(1, std::min(want, base - 1)) : 1;
+    const size_t bytes = c->field_floats * FLUID_NFIELDS * sizeof(float);
+    int rc = FLUID_OK;
+    auto bail = [&](int code) { fluid_destroy(c); return code; };
+    if (cfg->arena) {
+        if (cfg->arena_bytes < bytes) return bail(fail(FLUID_E_INVALID, "arena too small: %zu < %zu", cfg->arena_bytes, bytes));
+        if (((uintptr_t)cfg->arena & 255u) != 0) return bail(fail(FLUID_E_INVALID, "arena must be 256-byte aligned"));
+        c->arena = (float*)cfg->arena;
+    } else {
+        hipError_t e = hipMalloc((void**)&c->arena, bytes);
+        if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? FLUID_E_NOMEM : FLUID_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)));
+        c->own_arena = true;
+    }
+    if (cfg->stream) {
+        c->stream = (hipStream_t)cfg->stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return bail(fail(FLUID_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
+        c->own_stream = true;
+    }
+    for (int k = 0; k < FLUID_NFIELDS; ++k) c->f[k] = c->arena + (size_t)k * c->field_floats;
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        rc = fail(e == hipErrorOutOfMemory ? FLUID_E_NOMEM : FLUID_E_HIP, "%s: %s", what, hipGetErrorString(e));
+        return false;
+    };
+    if (!hip_ok(hipMemsetAsync(c->arena, 0, bytes, c->stream), "hipMemsetAsync(arena)")) return bail(rc);
+    if (!hip_ok(hipMalloc((void**)&c->d_scalar, 256), "hipMalloc(scalar)")) return bail(rc);
+    if (!hip_ok(hipHostMalloc((void**)&c->h_scalar, 256, hipHostMallocDefault), "hipHostMalloc")) return bail(rc);
+    if (!hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return bail(rc);
+    *out = c;
+    return FLUID_OK;
+}
+
+int fluid_create(int N, fluid_ctx** out)
+{
+    fluid_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.n = N;
+    cfg.nranks = 1;
+    return fluid_create_ex(&cfg, out);
+}
+
+int fluid_destroy(fluid_ctx* c)
+{
+    if (!c) return FLUID_OK;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->ev_pool) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    if (c->d_scalar) (void)hipFree(c->d_scalar);
+    if (c->h_scalar) (void)hipHostFree(c->h_scalar);
+    if (c->own_arena && c->arena) (void)hipFree(c->arena);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (g_cached == c) g_cached = nullptr;
+    delete c;
+    return FLUID_OK;
+}
+
+int fluid_synchronize(fluid_ctx* c)
+{
+    TRY(check_ctx(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FLUID_OK;
+}
+
+int fluid_owned_rows(fluid_ctx* c, int* row_lo, int* row_hi)
+{
+    TRY(check_ctx(c));
+    if (row_lo) *row_lo = c->own0;
+    if (row_hi) *row_hi = c->own1;
+    return FLUID_OK;
+}
+
+int fluid_field_ptr(fluid_ctx* c, int field, void** dev_ptr)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {field}));
+    if (!dev_ptr) return fail(FLUID_E_INVALID, "null pointer");
+    *dev_ptr = c->f[field];
+    return FLUID_OK;
+}
+
+int fluid_upload_rows(fluid_ctx* c, int field, const float* host, int row_lo, int row_hi)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {field}));
+    if (!host) return fail(FLUID_E_INVALID, "null host pointer");
+    return copy_rows(c, field, nullptr, host, row_lo, row_hi, true);
+}
+
+int fluid_download_rows(fluid_ctx* c, int field, float* host, int row_lo, int row_hi)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {field}));
+    if (!host) return fail(FLUID_E_INVALID, "null host pointer");
+    return copy_rows(c, field, host, nullptr, row_lo, row_hi, false);
+}
+
+int fluid_upload(fluid_ctx* c, int field, const float* host)
+{
+    TRY(check_ctx(c));
+    return fluid_upload_rows(c, field, host, 0, c->w);
+}
+
+int fluid_download(fluid_ctx* c, int field, float* host)
+{
+    TRY(check_ctx(c));
+    return fluid_download_rows(c, field, host, 0, c->w);
+}
+
+int fluid_fill(fluid_ctx* c, int field, float value)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {field}));
+    if (value == 0.0f && !std::signbit(value)) {
+        HIP_TRY(hipMemsetAsync(c->f[field], 0, c->field_floats * sizeof(float), c->stream));
+        return FLUID_OK;
+    }
+    std::vector<float> row((size_t)c->w * c->w, value);
+    return fluid_upload(c, field, row.data());
+}
+
+int fluid_set_jacobi_variant(fluid_ctx* c, int variant)
+{
+    TRY(check_ctx(c));
+    if (variant < 0 || variant >= fluid::JACOBI_VARIANTS) return fail(FLUID_E_INVALID, "unknown Jacobi variant %d", variant);
+    c->variant = variant;
+    return FLUID_OK;
+}
+
+int fluid_set_exchange(fluid_ctx* c, fluid_exchange_fn fn, void* user)
+{
+    TRY(check_ctx(c));
+    c->xchg = fn;
+    c->xchg_user = user;
+    return FLUID_OK;
+}
+
+int fluid_vel_step(fluid_ctx* c, float dt, float visc, int iters)
+{
+    TRY(check_ctx(c));
+    if (iters < 0 || (iters & 1)) return fail(FLUID_E_INVALID, "sweep count must be even and >= 0 (got %d)", iters);
+    TRY(vel_step(c, dt, visc, iters));
+    HIP_TRY(hipGetLastError());
+    return FLUID_OK;
+}
+
+int fluid_dens_step(fluid_ctx* c, float dt, float diff, int iters)
+{
+    TRY(check_ctx(c));
+    if (iters < 0 || (iters & 1)) return fail(FLUID_E_INVALID, "sweep count must be even and >= 0 (got %d)", iters);
+    TRY(dens_step(c, dt, diff, iters));
+    HIP_TRY(hipGetLastError());
+    return FLUID_OK;
+}
+
+int fluid_step(fluid_ctx* c, float dt, float diff, float visc, int iters, int nsteps, int use_sources)
+{
+    TRY(check_ctx(c));
+    if (iters < 0 || (iters & 1)) return fail(FLUID_E_INVALID, "sweep count must be even and >= 0 (got %d)", iters);
+    if (nsteps < 0) return fail(FLUID_E_INVALID, "nsteps < 0");
+    for (int z = 0; z < nsteps; ++z) {
+        if (!(use_sources && z == 0)) TRY(zero_sources(c));
+        TRY(vel_step(c, dt, visc, iters));
+        TRY(dens_step(c, dt, diff, iters));
+    }
+    HIP_TRY(hipGetLastError());
+    return FLUID_OK;
+}
+
+// ---- operators ---------------------------------------------------------------
+int fluid_op_set_bnd(fluid_ctx* c, int b, int x)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {x}));
+    if (b < 0 || b > 2) return fail(FLUID_E_INVALID, "b must be 0, 1 or 2");
+    if (c->nranks != 1) return fail(FLUID_E_INVALID, "fluid_op_set_bnd is a whole-grid operator (1 GPU)");
+    fluid::launch_set_bnd(c->stream, c->f[x], c->pitch, c->n, b);
+    HIP_TRY(hipGetLastError());
+    return FLUID_OK;
+}
+
+int fluid_op_add_source(fluid_ctx* c, int x, int s, float dt)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {x, s}));
+    if (x == s) return fail(FLUID_E_INVALID, "add_source: x and s must differ");
+    TRY(op_add_source(c, x, s, dt));
+    HIP_TRY(hipGetLastError());
+    return FLUID_OK;
+}
+
+int fluid_op_jacobi_sweep(fluid_ctx* c, int b, int x, int x0, int out, float alpha, float beta)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {x, x0, out}));
+    if (b < 0 || b > 2) return fail(FLUID_E_INVALID, "b must be 0, 1 or 2");
+    if (out == x || out == x0) return fail(FLUID_E_INVALID, "jacobi_sweep: out must not alias an input");
+    TRY(exchange(c, FLUID_XCHG_HALO, {x}, 1));
+    fluid::launch_jacobi(c->stream, c->variant, c->f[x], c->f[x0], c->f[out], c->pitch, c->n, c->own0, c->own1, alpha, beta, b);
+    HIP_TRY(hipGetLastError());
+    return FLUID_OK;
+}
+
+int fluid_op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int iters)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {x, x0}));
+    if (b < 0 || b > 2) return fail(FLUID_E_INVALID, "b must be 0, 1 or 2");
+    return op_diffuse(c, b, x, x0, alpha, beta, iters);
+}
+
+int fluid_op_advect(fluid_ctx* c, int b, int d, int d0, int u, int v, float dt)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {d, d0, u, v}));
+    if (b < 0 || b > 2) return fail(FLUID_E_INVALID, "b must be 0, 1 or 2");
+    if (d == d0 || d == u || d == v) return fail(FLUID_E_INVALID, "advect: output must not alias an input");
+    TRY(advect_prepare(c, {d0}, u, v, dt * (float)c->n));
+    TRY(op_advect(c, b, d, d0, u, v, dt));
+    HIP_TRY(hipGetLastError());
+    return FLUID_OK;
+}
+
+int fluid_op_divergence(fluid_ctx* c, int u, int v, int p, int div)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {u, v, p, div}));
+    TRY(exchange(c, FLUID_XCHG_HALO, {u, v}, 1));
+    TRY(op_divergence(c, u, v, p, div));
+    HIP_TRY(hipGetLastError());
+    return FLUID_OK;
+}
+
+int fluid_op_subtract_gradient(fluid_ctx* c, int u, int v, int p)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {u, v, p}));
+    TRY(exchange(c, FLUID_XCHG_HALO, {p}, 1));
+    TRY(op_subtract_gradient(c, u, v, p));
+    HIP_TRY(hipGetLastError());
+    return FLUID_OK;
+}
+
+// ---- diagnostics --------------------------------------------------------------
+int fluid_residual(fluid_ctx* c, int x, int x0, float alpha, float beta, float* out)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {x, x0}));
+    if (!out) return fail(FLUID_E_INVALID, "null pointer");
+    TRY(exchange(c, FLUID_XCHG_HALO, {x}, 1));
+    HIP_TRY(hipMemsetAsync(c->d_scalar, 0, sizeof(unsigned), c->stream));
+    fluid::launch_residual(c->stream, c->f[x], c->f[x0], c->pitch, c->n, c->own0, c->own1, alpha, beta, c->d_scalar);
+    TRY(reduce_to_host(c, out));
+    return exchange(c, FLUID_XCHG_MAX, {}, 0, out);
+}
+
+int fluid_absmax_velocity(fluid_ctx* c, int u, int v, float* out)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {u, v}));
+    if (!out) return fail(FLUID_E_INVALID, "null pointer");
+    HIP_TRY(hipMemsetAsync(c->d_scalar, 0, sizeof(unsigned), c->stream));
+    fluid::launch_absmax2(c->stream, c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, c->d_scalar);
+    TRY(reduce_to_host(c, out));
+    return exchange(c, FLUID_XCHG_MAX, {}, 0, out);
+}
+
+// ---- timing -------------------------------------------------------------------
+int fluid_timing_enable(fluid_ctx* c, int on)
+{
+    TRY(check_ctx(c));
+    TRY(timing_collect(c));
+    c->timing = on != 0;
+    return FLUID_OK;
+}
+
+int fluid_timing_read(fluid_ctx* c, fluid_timing* out, int reset)
+{
+    TRY(check_ctx(c));
+    if (!out) return fail(FLUID_E_INVALID, "null pointer");
+    TRY(timing_collect(c));
+    out->jacobi_ms = c->jacobi_ms;
+    out->sweeps = c->sweeps;
+    out->solves = c->solves;
+    if (reset) {
+        c->jacobi_ms = 0.0;
+        c->sweeps = c->solves = 0;
+    }
+    return FLUID_OK;
+}
+
+// ---- the reference's loop body on host arrays -----------------------------------
+int fluid_release_cached(void)
+{
+    fluid_ctx* c = g_cached;
+    g_cached = nullptr;
+    return fluid_destroy(c);
+}
+
+static int cached_ctx(int N, fluid_ctx** out)
+{
+    if (g_cached && g_cached->n != N) TRY(fluid_release_cached());
+    if (!g_cached) TRY(fluid_create(N, &g_cached));
+    *out = g_cached;
+    return FLUID_OK;
+}
+
+int step_src(int N, float dt, float diff, float visc, int iters, float* u, float* v, float* dens, float* u_prev,
+             float* v_prev, float* dens_prev)
+{
+    if (!u || !v || !dens || !u_prev || !v_prev || !dens_prev) return fail(FLUID_E_INVALID, "step_src: null field");
+    if (iters < 0 || (iters & 1)) return fail(FLUID_E_INVALID, "sweep count must be even and >= 0 (got %d)", iters);
+    fluid_ctx* c;
+    TRY(cached_ctx(N, &c));
+    float* host[6] = {u, v, dens, u_prev, v_prev, dens_prev};
+    for (int k = 0; k < 6; ++k) TRY(fluid_upload(c, k, host[k]));
+    TRY(fluid_step(c, dt, diff, visc, iters, 1, 1));
+    for (int k = 0; k < 6; ++k) TRY(fluid_download(c, k, host[k]));
+    return FLUID_OK;
+}
+
+int step(int N, float dt, float diff, float visc, float* u, float* v, float* dens)
+{
+    if (!u || !v || !dens) return fail(FLUID_E_INVALID, "step: null field");
+    fluid_ctx* c;
+    TRY(cached_ctx(N, &c));
+    float* host[3] = {u, v, dens};
+    for (int k = 0; k < 3; ++k) TRY(fluid_upload(c, k, host[k]));
+    TRY(fluid_step(c, dt, diff, visc, 40, 1, 0));   // 40 sweeps: FluidSequential.c:91
+    for (int k = 0; k < 3; ++k) TRY(fluid_download(c, k, host[k]));
+    return FLUID_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+"""Row-slab multi-GPU layer: one process (and one libfluid_amd context) per GPU.
+
+The reference is single-device (no NCCL/MPI anywhere), so this
+has no reference counterpart; what it must preserve is the result: every cell
+goes through the same arithmetic as on one GPU, so an N-GPU run is bit-identical
+to the 1-GPU run.
+
+Division of labour: the C++ orchestrator (csrc/fluid_solver.hip) decides *when*
+rows have to move and calls back; this module only moves them, with
+torch.distributed point-to-point ops (backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in the CPU tests) on torch tensors that alias the context's
+device arena.  Every rank keeps full-size fields (288 GB of HBM per GPU makes
+that free: 9 fields x 256 MiB at 8192^2), computes only its slab, and global row
+r is local row r -- so a halo is just rows [own-depth, own) and the advect
+fallback is an in-place all-gather.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+from .solver import FluidSolver
+
+
+def slab_rows(n, rank, nranks):
+    """Interior rows [lo, hi) of slab `rank` (same split as fluid_create_ex)."""
+    base, rem = divmod(n, nranks)
+    lo = 1 + rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class TorchExchange:
+    """The fluid_exchange_fn of include/fluid_amd.h over torch.distributed.
+
+    `fields[id]` is a [n+2, pitch] tensor view of field `id`; rows of it are
+    contiguous, so a halo needs no packing."""
+
+    def __init__(self, fields, n, rank, nranks, group=None):
+        self.fields, self.n, self.rank, self.nranks, self.group = fields, n, rank, nranks, group
+        self.lo, self.hi = slab_rows(n, rank, nranks)
+        self.calls = {capi.XCHG_HALO: 0, capi.XCHG_GATHER: 0, capi.XCHG_MAX: 0}
+
+    def _peer(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def __call__(self, kind, ids, depth, scalar):
+        self.calls[kind] += 1
+        if kind == capi.XCHG_HALO:
+            return self.halo(ids, depth)
+        if kind == capi.XCHG_GATHER:
+            return self.gather(ids)
+        if kind == capi.XCHG_MAX:
+            return self.maximum(scalar)
+        raise ValueError("unknown exchange kind %r" % kind)
+
+    def halo(self, ids, depth):
+        lo, hi = self.lo, self.hi
+        if depth < 1 or depth > hi - lo:
+            raise ValueError("halo depth %d does not fit slab of %d rows" % (depth, hi - lo))
+        ops = []
+        for fid in ids:             # same order on every rank: sends and receives pair up
+            f = self.fields[fid]
+            if self.rank > 0:
+                up = self._peer(self.rank - 1)
+                ops.append(dist.P2POp(dist.isend, f[lo:lo + depth], up, self.group))
+                ops.append(dist.P2POp(dist.irecv, f[lo - depth:lo], up, self.group))
+            if self.rank < self.nranks - 1:
+                dn = self._peer(self.rank + 1)
+                ops.append(dist.P2POp(dist.isend, f[hi - depth:hi], dn, self.group))
+                ops.append(dist.P2POp(dist.irecv, f[hi:hi + depth], dn, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def gather(self, ids):
+        for fid in ids:
+            f = self.fields[fid]
+            for r in range(self.nranks):
+                lo, hi = slab_rows(self.n, r, self.nranks)
+                lo -= 1 if r == 0 else 0                    # end slabs own the wall rows
+                hi += 1 if r == self.nranks - 1 else 0
+                dist.broadcast(f[lo:hi], src=self._peer(r), group=self.group)
+
+    def maximum(self, value):
+        t = torch.tensor([value], dtype=torch.float32, device=self.fields[0].device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+
+class SlabSolver(FluidSolver):
+    """FluidSolver for rank `rank` of `nranks`, device memory owned by torch so
+    RCCL can address it; kernels run on torch's current stream so the
+    collectives order against them without host synchronisation."""
+
+    def __init__(self, n, rank=None, nranks=None, halo=0, jacobi=capi.JACOBI_STREAM, device=None, group=None):
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if nranks is None:
+            nranks = dist.get_world_size(group) if dist.is_initialized() else 1
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("SlabSolver computes with HIP kernels only; got device %s" % device)
+        L = capi.lib()
+        nbytes = L.fluid_arena_bytes(n)
+        if nbytes == 0:
+            capi.check(capi.E_INVALID)
+        import ctypes as C
+        pitch, xoff, ff = C.c_int(), C.c_int(), C.c_size_t()
+        capi.check(L.fluid_layout(n, C.byref(pitch), C.byref(xoff), C.byref(ff)))
+        self.pitch, self.xoff = pitch.value, xoff.value
+        with torch.cuda.device(self.device):
+            self.arena = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.device)
+            stream = torch.cuda.current_stream().cuda_stream
+            super().__init__(n, rank=rank, nranks=nranks, halo=halo, jacobi=jacobi, stream=stream,
+                             arena_ptr=self.arena.data_ptr(), arena_bytes=nbytes)
+        self.fields = [self.arena[k * ff.value:(k + 1) * ff.value].view(n + 2, self.pitch)
+                       for k in range(capi.NFIELDS)]
+        self.exchange = None
+        if nranks > 1:
+            self.exchange = TorchExchange(self.fields, n, rank, nranks, group)
+            self.set_exchange(self.exchange)
+
+    def interior(self, field):
+        """[n+2, n+2] strided view of a field (ghost ring included)."""
+        fid = capi.FIELD_NAMES.index(field) if isinstance(field, str) else int(field)
+        return self.fields[fid][:, self.xoff:self.xoff + self.n + 2]
+
+    def load_global(self, **host_fields):
+        """Every rank uploads the rows it computes on (its slab + wall rows);
+        the rest of its copy stays zero until an exchange fills it."""
+        lo, hi = self.owned_rows
+        lo -= 1 if self.rank == 0 else 0
+        hi += 1 if self.rank == self.nranks - 1 else 0
+        for name, arr in host_fields.items():
+            self.upload_rows(name, arr, lo, hi)
+
+    def gather_global(self, field):
+        """Full field on every rank's host (tests / result collection):
+        an in-place all-gather of the slabs, then one download (bit preserving)."""
+        fid = capi.FIELD_NAMES.index(field) if isinstance(field, str) else int(field)
+        if self.nranks > 1:
+            self.exchange.gather([fid])
+        return self.download(fid)

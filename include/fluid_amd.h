@@ -1,0 +1,165 @@
+/*
+ * fluid_amd.h -- C ABI of the MI355X Stable-Fluids step (libfluid_amd.so).
+ *
+ * Drop-in boundary for the vel_step + dens_step hot path of the reference's
+ * project/sequential/FluidSequential.c.  The reference has no library or FFI
+ * interface of its own: its boundary is the two calls at FluidSequential.c:305-306
+ * with N, DT, VIS, DIFF as compile-time macros (:6-9).  Each entry point below
+ * cites the reference lines whose behaviour it reproduces.  Plain C types only.
+ *
+ * Host arrays ("fields") are what the reference's main() allocates (:277-282):
+ * (N+2)*(N+2) floats, row-major, cell (column j, row i) at j + i*(N+2), ghost
+ * ring at index 0 and N+1.  The caller owns them; the library owns all device
+ * memory and scratch and never allocates per step.
+ *
+ * Every function returns FLUID_OK (0) or a FLUID_E_* code and never exits or
+ * aborts (the reference's CUDA variants exit(EXIT_FAILURE) in their CHECK
+ * macro, naivePar/FluidParallelBlockPerElement-Naive.cu:26-35).
+ * fluid_last_error() returns a description of the calling thread's last failure.
+ *
+ * Threading: one context is used by one host thread at a time; different
+ * contexts are independent.
+ */
+#ifndef FLUID_AMD_H
+#define FLUID_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLUID_OK        0
+#define FLUID_E_INVALID 1 /* bad N, odd or negative sweep count, null pointer, bad field id */
+#define FLUID_E_NOMEM   2 /* device or host allocation failed */
+#define FLUID_E_HIP     3 /* a HIP runtime call failed */
+#define FLUID_E_COMM    4 /* the multi-GPU exchange callback failed or is missing */
+
+/* Field ids of a context = the six arrays of the reference's main()
+ * (FluidSequential.c:277-282) plus three library-owned scratch fields. */
+enum {
+    FLUID_U = 0, FLUID_V = 1, FLUID_DENS = 2,
+    FLUID_U_PREV = 3, FLUID_V_PREV = 4, FLUID_DENS_PREV = 5,
+    FLUID_TMP0 = 6, FLUID_TMP1 = 7, FLUID_TMP2 = 8,
+    FLUID_NFIELDS = 9
+};
+
+/* Jacobi sweep kernels (identical results, different data paths). */
+enum { FLUID_JACOBI_STREAM = 0, FLUID_JACOBI_LDS = 1, FLUID_JACOBI_NAIVE = 2 };
+
+typedef struct fluid_ctx fluid_ctx;
+
+const char *fluid_last_error(void);
+
+/* ---- the reference's loop body on host arrays ----------------------------
+ * step():     FluidSequential.c:298-306 for z > 0 -- the three *_prev source
+ *             arrays are zero, then vel_step(u,v,u_prev,v_prev,visc) and
+ *             dens_step(dens,dens_prev,u,v,diff), 40 Jacobi sweeps per solve
+ *             (:91).  u, v, dens are updated in place.
+ * step_src(): FluidSequential.c:305-306 verbatim, sources supplied by the
+ *             caller (the z == 0 step).  On return u_prev holds the last
+ *             pressure, v_prev the last divergence and dens_prev the diffused
+ *             density, exactly where the reference leaves them (SWAPs at
+ *             :201,209,228-229,181,184).  `iters` must be even and >= 0: with an
+ *             odd count the reference free()s the caller's array (:100,103).
+ * Both keep a per-thread cached context for the last N, upload, run one step
+ * on the current HIP device, and download. */
+int step(int N, float dt, float diff, float visc, float *u, float *v, float *dens);
+int step_src(int N, float dt, float diff, float visc, int iters,
+             float *u, float *v, float *dens,
+             float *u_prev, float *v_prev, float *dens_prev);
+/* Drops the cached context of step()/step_src() (frees its device memory). */
+int fluid_release_cached(void);
+
+/* alpha = ((dt*coef)*N)*N, beta = 1 + 4*alpha in float (FluidSequential.c:179-180,199-200). */
+int fluid_coefficients(int N, float dt, float coef, float *alpha, float *beta);
+
+/* ---- device-resident context --------------------------------------------- */
+typedef struct fluid_config {
+    int n;              /* interior size N (grid is (N+2)^2), N >= 1                    */
+    int rank, nranks;   /* row-slab decomposition: this context owns slab `rank` of `nranks` */
+    int halo;           /* Jacobi ghost-zone depth between exchanges (0 = default)      */
+    int jacobi_variant; /* FLUID_JACOBI_*                                               */
+    void *stream;       /* hipStream_t to run on, or NULL for a library-owned stream    */
+    void *arena;        /* device memory of fluid_arena_bytes(n) bytes, or NULL to hipMalloc */
+    size_t arena_bytes;
+} fluid_config;
+
+size_t fluid_arena_bytes(int N);
+/* Device layout of one field: W = N+2 rows of `pitch` floats, column c at
+ * float index c + xoff; field f starts f*field_floats floats into the arena. */
+int fluid_layout(int N, int *pitch, int *xoff, size_t *field_floats);
+
+int fluid_create(int N, fluid_ctx **out);                      /* 1 GPU, defaults */
+int fluid_create_ex(const fluid_config *cfg, fluid_ctx **out);
+int fluid_destroy(fluid_ctx *ctx);
+int fluid_synchronize(fluid_ctx *ctx);
+
+/* Interior rows [*row_lo, *row_hi) owned by this context's slab (1..N+1 for one GPU). */
+int fluid_owned_rows(fluid_ctx *ctx, int *row_lo, int *row_hi);
+/* Device address of row 0 of a field (for the exchange callback). */
+int fluid_field_ptr(fluid_ctx *ctx, int field, void **dev_ptr);
+
+/* Host <-> device copies of a whole field, or of rows [row_lo,row_hi) of it
+ * (host pointer is always to the full (N+2)^2 array). Synchronous. */
+int fluid_upload(fluid_ctx *ctx, int field, const float *host);
+int fluid_download(fluid_ctx *ctx, int field, float *host);
+int fluid_upload_rows(fluid_ctx *ctx, int field, const float *host, int row_lo, int row_hi);
+int fluid_download_rows(fluid_ctx *ctx, int field, float *host, int row_lo, int row_hi);
+int fluid_fill(fluid_ctx *ctx, int field, float value);
+
+/* nsteps loop bodies of FluidSequential.c:289-312 on the resident fields.  With
+ * use_sources != 0 the first step consumes the resident *_prev fields as
+ * sources (z == 0); every other step zeroes them first (:298-302). */
+int fluid_step(fluid_ctx *ctx, float dt, float diff, float visc, int iters,
+               int nsteps, int use_sources);
+int fluid_vel_step(fluid_ctx *ctx, float dt, float visc, int iters);   /* FluidSequential.c:189-241 */
+int fluid_dens_step(fluid_ctx *ctx, float dt, float diff, int iters);  /* FluidSequential.c:176-186 */
+
+/* ---- single operators on resident fields (field ids; all in place) -------- */
+int fluid_op_set_bnd(fluid_ctx *ctx, int b, int x);                               /* :62-75   */
+int fluid_op_add_source(fluid_ctx *ctx, int x, int s, float dt);                  /* :78-82   */
+int fluid_op_jacobi_sweep(fluid_ctx *ctx, int b, int x, int x0, int out,
+                          float alpha, float beta);                               /* :92-101, one k */
+int fluid_op_diffuse(fluid_ctx *ctx, int b, int x, int x0, float alpha, float beta,
+                     int iters);                                                  /* :85-104; uses TMP0 */
+int fluid_op_advect(fluid_ctx *ctx, int b, int d, int d0, int u, int v, float dt); /* :107-141 */
+int fluid_op_divergence(fluid_ctx *ctx, int u, int v, int p, int div);            /* :143-158 */
+int fluid_op_subtract_gradient(fluid_ctx *ctx, int u, int v, int p);              /* :161-173 */
+
+/* ---- diagnostics (wavefront reductions; never alter the fields) ----------- */
+/* max over owned interior cells of |beta*x - alpha*(L+R+U+D) - x0| */
+int fluid_residual(fluid_ctx *ctx, int x, int x0, float alpha, float beta, float *out);
+/* max over owned interior cells of max(|u|,|v|) */
+int fluid_absmax_velocity(fluid_ctx *ctx, int u, int v, float *out);
+
+int fluid_set_jacobi_variant(fluid_ctx *ctx, int variant);
+
+/* ---- timing: HIP events on the context's stream around every Jacobi solve -- */
+typedef struct fluid_timing {
+    double jacobi_ms;      /* device time inside Jacobi solves since the last reset */
+    long long sweeps;      /* Jacobi sweeps executed in those solves                */
+    long long solves;
+} fluid_timing;
+int fluid_timing_enable(fluid_ctx *ctx, int on);
+int fluid_timing_read(fluid_ctx *ctx, fluid_timing *out, int reset);
+
+/* ---- multi-GPU: row slabs, one context (and one process) per GPU ----------
+ * The solver calls back whenever rows must move between slabs; the host layer
+ * implements it with RCCL (torch.distributed) on the context's stream.
+ *   FLUID_XCHG_HALO  : for each listed field, send `depth` owned rows at each
+ *                      slab edge to that neighbour and receive its rows into
+ *                      the rows just outside the owned range.
+ *   FLUID_XCHG_GATHER: all-gather the owned rows (end slabs: plus the ghost
+ *                      row) of each listed field, so every rank holds the full field.
+ *   FLUID_XCHG_MAX   : *scalar = max over ranks of *scalar.
+ * Return 0 on success. */
+enum { FLUID_XCHG_HALO = 0, FLUID_XCHG_GATHER = 1, FLUID_XCHG_MAX = 2 };
+typedef int (*fluid_exchange_fn)(void *user, int kind, const int *fields, int nfields,
+                                 int depth, float *scalar);
+int fluid_set_exchange(fluid_ctx *ctx, fluid_exchange_fn fn, void *user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUID_AMD_H */
