@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: Mcells/s per Jacobi iteration
+and ms per simulation step of the Stable-Fluids vel_step + dens_step.
+
+  python bench.py [--gpus N --steps K --warmup W]      (N>1: under torch.distributed.run)
+
+A "step" is one loop body of the reference's main (FluidSequential.c:298-306):
+sources zeroed, vel_step, dens_step, 40 Jacobi sweeps per solve = 200 sweeps,
+3 advects, 2 projections.  Fields are resident in HBM when the timed region
+starts.  One JSON line on rank 0.
+
+Workload: N=1 -> 4096^2 (the grid BASELINE.json's metric is quoted on, config
+2); N>1 -> 8192^2 split into row slabs (config 3), strong scaling.  The N=1
+line also carries the 1-GPU 8192^2 measurement ("scaling_base") so the 8192^2
+speed-up can be formed from the driver's own runs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+BYTES_PER_CELL_SWEEP = 12      # read x + read x0 + write x_new, fp32
+BYTES_PER_CELL_STEP = 2548     # SURVEY.md 8(d), 40 sweeps/solve
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=0, help="grid width W=N+2 (default 4096 on 1 GPU, 8192 on several)")
+    ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--variant", type=int, default=0, help="Jacobi kernel: 0 stream, 1 LDS-tiled, 2 naive")
+    ap.add_argument("--halo", type=int, default=0, help="multi-GPU ghost-zone depth (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scaling-base", action="store_true")
+    ap.add_argument("--seed", type=int, default=1)
+    return ap.parse_args()
+
+
+def measure(solver, dist, world, steps, warmup, iters, cells):
+    """W untimed steps, then exactly K timed steps between barrier+synchronize
+    pairs; returns (max-over-ranks seconds, max-over-ranks Jacobi ms, sweeps)."""
+    import torch
+    solver.step(1, use_sources=True, iters=iters)          # z == 0 consumes the synthetic sources
+    for _ in range(max(warmup - 1, 0)):
+        solver.step(1, iters=iters)
+    solver.timing_enable(True)
+    solver.timing_read(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    solver.step(steps, iters=iters)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = solver.timing_read(reset=True)
+    solver.timing_enable(False)
+    jac_ms, sweeps = t["jacobi_ms"], t["sweeps"]
+    if world > 1:
+        buf = torch.tensor([elapsed, jac_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX)
+        elapsed, jac_ms = float(buf[0]), float(buf[1])
+    return elapsed, jac_ms, sweeps
+
+
+def cpu_baseline(n, fields, iters):
+    """The oracle leg (checker only): one full step and one 40-sweep pressure
+    solve on ONE host core at the bench workload's N -- the reference itself
+    (oracle/_ref, kind "reference") when its build for this N travelled here,
+    else the restatement (kind "port")."""
+    import numpy as np
+    from oracle.oracle import Oracle, Reference, have_ref
+    f = {k: v.copy() for k, v in fields.items()}
+    use_ref = have_ref(n, iters)
+    eng = Reference(n, iters) if use_ref else Oracle()
+    w = n + 2
+    t0 = time.perf_counter()
+    if use_ref:
+        eng.step_src(f["u"], f["v"], f["dens"], f["u_prev"], f["v_prev"], f["dens_prev"])
+    else:
+        eng.step_src(f["u"], f["v"], f["dens"], f["u_prev"], f["v_prev"], f["dens_prev"], iters=iters)
+    t_step = time.perf_counter() - t0
+    p, div = np.zeros((w, w), np.float32), f["v_prev"]
+    t0 = time.perf_counter()
+    if use_ref:
+        eng.diffuse(0, p, div, 1.0, 4.0)
+    else:
+        eng.diffuse(0, p, div, 1.0, 4.0, iters)
+    t_solve = time.perf_counter() - t0
+    return {"value": w * w / (t_solve / iters) / 1e6, "unit": "Mcells/s per Jacobi iter", "cores": 1,
+            "kind": "reference" if use_ref else "port", "ms_per_step": t_step * 1e3,
+            "sample": "1 full step (200 sweeps) + one %d-sweep pressure solve at %dx%d, gcc -O2, 1 thread"
+                      % (iters, w, w)}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from fluidsimulationcuda_amd.harness import initialize_parameters
+    from fluidsimulationcuda_amd.slab import SlabSolver
+
+    grid = a.grid or (4096 if world == 1 else 8192)
+    n = grid - 2
+    cells = grid * grid
+
+    def run(n_, steps, warmup):
+        fields = initialize_parameters(n_, seed=a.seed)     # same seed on every rank
+        s = SlabSolver(n_, rank=rank, nranks=world, halo=a.halo, jacobi=a.variant)
+        s.load_global(**fields)
+        out = measure(s, dist, world, steps, warmup, a.iters, (n_ + 2) ** 2)
+        calls = dict(s.exchange.calls) if s.exchange else None
+        s.close()
+        return out, fields, calls
+
+    (elapsed, jac_ms, sweeps), fields, calls = run(n, a.steps, a.warmup)
+    ms_step = elapsed * 1e3 / a.steps
+    t_sweep = jac_ms * 1e-3 / max(sweeps, 1)
+    mcells = cells / t_sweep / 1e6
+    achieved = BYTES_PER_CELL_SWEEP * cells / t_sweep / 1e9
+    line = {
+        "metric": "Mcells/s per Jacobi iter", "value": mcells, "unit": "Mcells/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (initializeParameters recipe, PCG64 seed %d)" % a.seed,
+        "config": {"workload": "%dx%d grid, full vel_step+dens_step, %d Jacobi sweeps/solve (200/step), fp32"
+                               % (grid, grid, a.iters),
+                   "grid": grid, "iters": a.iters, "jacobi_kernel": ["stream", "lds", "naive"][a.variant],
+                   "parallelism": "1 GPU" if world == 1 else "row slabs x%d, RCCL halo rows" % world},
+        "ms_per_sim_step": ms_step,
+        "us_per_jacobi_sweep": t_sweep * 1e6,
+        "step_algorithmic_GBps": BYTES_PER_CELL_STEP * cells / (ms_step * 1e-3) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": "k_jacobi_%s (one sweep + fused set_bnd)" % ["stream", "lds", "naive"][a.variant],
+                     "achieved": achieved * (1.0 / world), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / world / HBM_PEAK_GBS, "traffic": None,
+                     "note": "per GPU: 12 B/cell x %d cells/launch / mean launch time over %d timed launches (HIP events)"
+                             % (cells // world, sweeps)},
+    }
+    if calls:
+        line["exchanges_per_rank"] = {"halo": calls[0], "gather": calls[1], "max": calls[2]}
+    if world == 1 and not a.no_scaling_base and grid != 8192:
+        (e2, j2, s2), _, _ = run(8190, max(a.steps // 4, 3), 2)
+        ts2 = j2 * 1e-3 / max(s2, 1)
+        line["scaling_base"] = {"workload": "8192x8192 on 1 GPU", "value": 8192 * 8192 / ts2 / 1e6, "unit": "Mcells/s",
+                                "ms_per_step": e2 * 1e3 / max(a.steps // 4, 3),
+                                "roofline_frac": BYTES_PER_CELL_SWEEP * 8192 * 8192 / ts2 / 1e9 / HBM_PEAK_GBS}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(n, fields, a.iters)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

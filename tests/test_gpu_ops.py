@@ -1,0 +1,202 @@
+"""GPU: every operator of the hot path, through the C ABI, against the oracle
+(fresh random inputs) and the committed golden vectors from the compiled
+reference.  Bar: bit-exact (stricter than the 1e-5 relative of north_star)."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal, load_golden, rnd
+
+pytestmark = pytest.mark.gpu
+
+DT, VISC, DIFF = 0.016, 0.0025, 0.1
+SIZES = [1, 2, 3, 4, 5, 14, 30, 61, 64, 126, 255, 256, 257, 1022]
+VARIANTS = [0, 1, 2]          # stream, LDS-tiled, naive-global
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fluidsimulationcuda_amd as F
+    return F
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_set_bnd(F, oracle, n):
+    rng = np.random.default_rng(n)
+    with F.FluidSolver(n) as s:
+        for b in (0, 1, 2):
+            x = rnd(rng, n)
+            s.upload(u=x)
+            s.set_bnd(b, "u")
+            want = x.copy()
+            oracle.set_bnd(b, want)
+            assert_bit_equal(s.download("u"), want, "set_bnd n=%d b=%d" % (n, b))
+
+
+@pytest.mark.parametrize("n", [1, 14, 61, 255, 1022])
+def test_add_source(F, oracle, n):
+    rng = np.random.default_rng(n)
+    x, src = rnd(rng, n), rnd(rng, n)
+    with F.FluidSolver(n) as s:
+        s.upload(u=x, u_prev=src)
+        s.add_source("u", "u_prev", DT)
+        want = x.copy()
+        oracle.add_source(want, src, DT)
+        assert_bit_equal(s.download("u"), want, "add_source")
+        assert_bit_equal(s.download("u_prev"), src, "source untouched")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("n", SIZES)
+def test_jacobi_single_sweep(F, oracle, n, variant):
+    rng = np.random.default_rng(100 + n)
+    with F.FluidSolver(n, jacobi=variant) as s:
+        for b, (alpha, beta) in ((0, (1.0, 4.0)), (1, F.coefficients(n, DT, VISC)), (2, F.coefficients(n, DT, DIFF))):
+            x, x0, stale = rnd(rng, n), rnd(rng, n), rnd(rng, n)
+            s.upload(u=x, v=x0, dens=stale)
+            s.jacobi_sweep(b, "u", "v", "dens", alpha, beta)
+            want = stale.copy()
+            oracle.jacobi_sweep(b, x, x0, want, alpha, beta)
+            assert_bit_equal(s.download("dens"), want, "sweep n=%d b=%d variant=%d" % (n, b, variant))
+            assert_bit_equal(s.download("u"), x, "x untouched")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("n", [3, 30, 126, 257])
+def test_diffuse_40(F, oracle, n, variant):
+    rng = np.random.default_rng(200 + n)
+    with F.FluidSolver(n, jacobi=variant) as s:
+        for b, coef in ((1, VISC), (2, VISC), (0, DIFF), (0, None)):
+            alpha, beta = (1.0, 4.0) if coef is None else F.coefficients(n, DT, coef)
+            x, x0 = rnd(rng, n), rnd(rng, n)
+            s.upload(u=x, v=x0)
+            s.diffuse(b, "u", "v", alpha, beta, 40)
+            want = x.copy()
+            oracle.diffuse(b, want, x0, alpha, beta, 40)
+            assert_bit_equal(s.download("u"), want, "diffuse n=%d b=%d" % (n, b))
+
+
+def test_diffuse_rejects_odd_and_aliases(F):
+    from fluidsimulationcuda_amd import capi
+    with F.FluidSolver(14) as s:
+        for bad in (1, 39, -2):
+            with pytest.raises(capi.FluidError) as e:
+                s.diffuse(0, "u", "v", 1.0, 4.0, bad)
+            assert e.value.code == capi.E_INVALID
+        with pytest.raises(capi.FluidError):
+            s.diffuse(0, "u", "u", 1.0, 4.0, 2)
+        with pytest.raises(capi.FluidError):
+            s.diffuse(3, "u", "v", 1.0, 4.0, 2)
+        with pytest.raises(capi.FluidError):
+            s.advect(0, "u", "u", "v", "dens")
+        x = np.ones((16, 16), np.float32)
+        s.upload(u=x)
+        s.diffuse(0, "u", "v", 1.0, 4.0, 0)          # zero sweeps: no-op
+        assert_bit_equal(s.download("u"), x, "zero sweeps")
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_divergence_and_gradient(F, oracle, n):
+    rng = np.random.default_rng(300 + n)
+    with F.FluidSolver(n) as s:
+        u, v, p, d = rnd(rng, n), rnd(rng, n), rnd(rng, n), rnd(rng, n)
+        s.upload(u=u, v=v, u_prev=p, v_prev=d)
+        s.computeDivergenceAndPressure("u", "v", "u_prev", "v_prev")
+        oracle.divergence(u, v, p, d)
+        assert_bit_equal(s.download("u_prev"), p, "p cleared incl. ghosts")
+        assert_bit_equal(s.download("v_prev"), d, "div")
+        p = rnd(rng, n)
+        s.upload(u_prev=p)
+        s.lastProject("u", "v", "u_prev")
+        oracle.subtract_gradient(u, v, p)
+        assert_bit_equal(s.download("u"), u, "u - grad p")
+        assert_bit_equal(s.download("v"), v, "v - grad p")
+
+
+@pytest.mark.parametrize("amp", [0.0, 0.01, 1.0, 250.0])
+@pytest.mark.parametrize("n", [1, 2, 5, 30, 61, 256, 1022])
+def test_advect(F, oracle, n, amp):
+    """amp=0: identity on the interior; amp=250: dt0*|vel| spans the grid, all
+    four clamps hit (FluidSequential.c:117-127)."""
+    rng = np.random.default_rng(400 + n)
+    u, v, d0 = rnd(rng, n, -amp, amp), rnd(rng, n, -amp, amp), rnd(rng, n)
+    with F.FluidSolver(n) as s:
+        for b in (0, 1, 2):
+            s.upload(u=u, v=v, dens_prev=d0, dens=rnd(rng, n))
+            s.advect(b, "dens", "dens_prev", "u", "v", DT)
+            want = np.zeros_like(d0)
+            oracle.advect(b, want, d0, u, v, DT)
+            got = s.download("dens")
+            assert_bit_equal(got, want, "advect n=%d b=%d amp=%g" % (n, b, amp))
+            if amp == 0.0:
+                assert_bit_equal(got[1:-1, 1:-1], d0[1:-1, 1:-1], "zero velocity => identity")
+        # self-advection as in vel_step (FluidSequential.c:232,237): d0 aliases u / v
+        s.upload(u_prev=u, v_prev=v)
+        s.advect(1, "u", "u_prev", "u_prev", "v_prev", DT)
+        s.advect(2, "v", "v_prev", "u_prev", "v_prev", DT)
+        wu, wv = np.zeros_like(u), np.zeros_like(u)
+        oracle.advect(1, wu, u, u, v, DT)
+        oracle.advect(2, wv, v, u, v, DT)
+        assert_bit_equal(s.download("u"), wu, "self-advect u")
+        assert_bit_equal(s.download("v"), wv, "self-advect v")
+
+
+@pytest.mark.parametrize("n", [14, 30, 61])
+def test_golden_operators(F, n):
+    """The same vectors the oracle is pinned with, straight against the GPU."""
+    g = load_golden("ops_n%d.npz" % n)
+    with F.FluidSolver(n) as s:
+        for b in (0, 1, 2):
+            s.upload(u=g["bnd_in"])
+            s.set_bnd(b, "u")
+            assert_bit_equal(s.download("u"), g["bnd_out_b%d" % b], "golden set_bnd")
+        s.upload(u=g["src_x"], v=g["src_s"])
+        s.add_source("u", "v", DT)
+        assert_bit_equal(s.download("u"), g["src_out"], "golden add_source")
+        for k, (b, a, be) in enumerate(g["dif_params"]):
+            for iters in (2, 40):
+                for variant in VARIANTS:
+                    s.set_jacobi_variant(variant)
+                    s.upload(u=g["dif%d_x" % k], v=g["dif%d_x0" % k])
+                    s.diffuse(int(b), "u", "v", float(np.float32(a)), float(np.float32(be)), iters)
+                    assert_bit_equal(s.download("u"), g["dif%d_out%d" % (k, iters)], "golden diffuse %d/%d" % (k, iters))
+        s.set_jacobi_variant(0)
+        s.upload(u=g["div_u"], v=g["div_v"], u_prev=g["div_p_in"], v_prev=g["div_div_in"])
+        s.computeDivergenceAndPressure("u", "v", "u_prev", "v_prev")
+        assert_bit_equal(s.download("u_prev"), g["div_p"], "golden p")
+        assert_bit_equal(s.download("v_prev"), g["div_div"], "golden div")
+        s.upload(u=g["grad_u"], v=g["grad_v"], u_prev=g["grad_p"])
+        s.lastProject("u", "v", "u_prev")
+        assert_bit_equal(s.download("u"), g["grad_u_out"], "golden grad u")
+        assert_bit_equal(s.download("v"), g["grad_v_out"], "golden grad v")
+        for tag in ("small", "clamp"):
+            s.upload(u=g["adv_%s_u" % tag], v=g["adv_%s_v" % tag], dens_prev=g["adv_%s_d0" % tag])
+            for b in (0, 1, 2):
+                s.advect(b, "dens", "dens_prev", "u", "v", DT)
+                assert_bit_equal(s.download("dens"), g["adv_%s_out_b%d" % (tag, b)], "golden advect")
+            s.upload(u_prev=g["adv_%s_u" % tag], v_prev=g["adv_%s_v" % tag])
+            s.advect(1, "u", "u_prev", "u_prev", "v_prev", DT)
+            assert_bit_equal(s.download("u"), g["adv_%s_self_u" % tag], "golden self-advect u")
+            s.upload(u=g["adv_%s_u" % tag])
+            s.advect(2, "v", "v_prev", "u_prev", "v_prev", DT)
+            assert_bit_equal(s.download("v"), g["adv_%s_self_v" % tag], "golden self-advect v")
+
+
+def test_reductions(F, oracle):
+    n = 300
+    rng = np.random.default_rng(9)
+    u, v = rnd(rng, n, -3, 3), rnd(rng, n, -5, 5)
+    with F.FluidSolver(n) as s:
+        s.upload(u=u, v=v)
+        want = max(np.abs(u[1:-1, 1:-1]).max(), np.abs(v[1:-1, 1:-1]).max())
+        assert s.absmax_velocity("u", "v") == want
+        # residual is a diagnostic: compare against a float64 evaluation loosely,
+        # and check it falls as the solve proceeds and leaves the fields alone
+        x, x0 = rnd(rng, n), rnd(rng, n)
+        s.upload(u=x, v=x0)
+        r0 = s.residual("u", "v", 1.0, 4.0)
+        nb = x[1:-1, :-2] + x[1:-1, 2:] + x[:-2, 1:-1] + x[2:, 1:-1]
+        ref = np.abs(4.0 * x[1:-1, 1:-1].astype(np.float64) - nb - x0[1:-1, 1:-1]).max()
+        assert abs(r0 - ref) <= 1e-5 * ref
+        assert_bit_equal(s.download("u"), x, "residual must not alter x")
+        s.diffuse(0, "u", "v", 1.0, 4.0, 40)
+        assert s.residual("u", "v", 1.0, 4.0) < r0

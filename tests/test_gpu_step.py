@@ -1,0 +1,166 @@
+"""GPU: whole vel_step + dens_step through the C ABI against the golden
+snapshots from the compiled reference, the oracle at mid sizes, the reference's
+checksums at 1022/4094, and size-independent properties at full size."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_bit_equal, assert_close_fp32, load_golden, rnd
+
+pytestmark = pytest.mark.gpu
+DT, VISC, DIFF = 0.016, 0.0025, 0.1
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fluidsimulationcuda_amd as F
+    return F
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("n,iters,steps", [(30, 40, (1, 2, 5)), (61, 40, (1, 2, 5)), (126, 40, (1, 2, 5)),
+                                           (126, 20, (1, 2))])
+def test_golden_steps(F, n, iters, steps, variant):
+    g = load_golden("step_n%d_k%d.npz" % (n, iters))
+    z0 = np.zeros((n + 2, n + 2), np.float32)
+    with F.FluidSolver(n, jacobi=variant) as s:
+        s.upload(u=z0, v=z0, dens=z0, u_prev=g["init_u_prev"], v_prev=g["init_v_prev"], dens_prev=g["init_dens_prev"])
+        for z in range(1, max(steps) + 1):
+            s.step(1, use_sources=(z == 1), iters=iters)
+            if z == 1:
+                assert_bit_equal(s.download("u_prev"), g["s1_u_prev"], "pressure in u_prev")
+                assert_bit_equal(s.download("v_prev"), g["s1_v_prev"], "divergence in v_prev")
+                assert_bit_equal(s.download("dens_prev"), g["s1_dens_prev"], "diffused density in dens_prev")
+            if z in steps:
+                for name in ("u", "v", "dens"):
+                    got, want = s.download(name), g["s%d_%s" % (z, name)]
+                    assert_close_fp32(got, want, "%s step %d (contract: 1e-5 rel)" % (name, z))
+                    assert_bit_equal(got, want, "%s after step %d, n=%d" % (name, z, n))
+
+
+def test_multi_step_call_equals_single_steps(F):
+    g = load_golden("step_n61_k40.npz")
+    z0 = np.zeros((63, 63), np.float32)
+    with F.FluidSolver(61) as s:
+        s.upload(u=z0, v=z0, dens=z0, u_prev=g["init_u_prev"], v_prev=g["init_v_prev"], dens_prev=g["init_dens_prev"])
+        s.step(5, use_sources=True)
+        for name in ("u", "v", "dens"):
+            assert_bit_equal(s.download(name), g["s5_%s" % name], name)
+
+
+def test_host_array_drop_in(F):
+    """step()/step_src(): the C ABI on caller-owned host arrays
+    (FluidSequential.c:298-306), including a change of N between calls."""
+    for n in (30, 126):
+        g = load_golden("step_n%d_k40.npz" % n)
+        u, v, d = (np.zeros((n + 2, n + 2), np.float32) for _ in range(3))
+        u0, v0, d0 = g["init_u_prev"].copy(), g["init_v_prev"].copy(), g["init_dens_prev"].copy()
+        F.step_src(n, DT, DIFF, VISC, 40, u, v, d, u0, v0, d0)
+        assert_bit_equal(u, g["s1_u"], "step_src u")
+        assert_bit_equal(d, g["s1_dens"], "step_src dens")
+        assert_bit_equal(u0, g["s1_u_prev"], "step_src leaves p in u_prev")
+        F.step(n, DT, DIFF, VISC, u, v, d)
+        assert_bit_equal(u, g["s2_u"], "step u")
+        assert_bit_equal(v, g["s2_v"], "step v")
+        assert_bit_equal(d, g["s2_dens"], "step dens")
+    from fluidsimulationcuda_amd import capi
+    with pytest.raises(capi.FluidError):
+        F.step_src(30, DT, DIFF, VISC, 7, *(np.zeros((32, 32), np.float32) for _ in range(6)))
+    capi.check(capi.lib().fluid_release_cached())
+
+
+@pytest.mark.parametrize("n", [254, 1022])
+def test_step_vs_oracle(F, oracle, n):
+    dens, dens0, u, u0, v, v0 = oracle.initialize_portable(n, seed=n)
+    with F.FluidSolver(n) as s:
+        s.upload(u=u, v=v, dens=dens, u_prev=u0, v_prev=v0, dens_prev=dens0)
+        s.step(1, use_sources=True)
+        oracle.step_src(u, v, dens, u0, v0, dens0)
+        s.step(1)
+        oracle.step(u, v, dens, u0, v0, dens0)
+        for name, want in (("u", u), ("v", v), ("dens", dens), ("u_prev", u0), ("v_prev", v0), ("dens_prev", dens0)):
+            assert_bit_equal(s.download(name), want, "%s n=%d" % (name, n))
+
+
+def _fnv1a(a):
+    hv, pv, mask = 0xCBF29CE484222325, 0x100000001B3, (1 << 64) - 1
+    for x in np.ascontiguousarray(a).view(np.uint32).ravel().tolist():
+        hv = ((hv ^ x) * pv) & mask
+    return hv
+
+
+@pytest.mark.parametrize("n", [1022, 4094])
+def test_reference_checksums(F, oracle, n):
+    """Step 1 from the reference's own initializeParameters (glibc rand seed 1):
+    sums, centre values and FNV-1a of the reference's output (checksums.json)."""
+    row = [r for r in json.load(open(os.path.join(GOLDEN, "checksums.json"))) if r["n"] == n][0]
+    dens, dens0, u, u0, v, v0 = oracle.initialize_glibc(n, seed=1)
+    with F.FluidSolver(n) as s:
+        s.upload(u=u, v=v, dens=dens, u_prev=u0, v_prev=v0, dens_prev=dens0)
+        s.step(1, use_sources=True)
+        gu, gv, gd = s.download("u"), s.download("v"), s.download("dens")
+    c = (n + 2) // 2
+    assert float(gu.sum(dtype=np.float64)) == row["sum_u"]
+    assert float(gv.sum(dtype=np.float64)) == row["sum_v"]
+    assert float(gd.sum(dtype=np.float64)) == row["sum_dens"]
+    assert float(gu[c, c]) == row["u_c"] and float(gd[c, c]) == row["dens_c"]
+    if n <= 1022:      # the pure-python hash is slow; sums + centre pin 4094
+        assert _fnv1a(gu) == row["fnv_u"] and _fnv1a(gv) == row["fnv_v"] and _fnv1a(gd) == row["fnv_dens"]
+
+
+def test_properties_at_full_size(F):
+    """4096^2 (BASELINE config 3): properties that need no CPU run.
+    - a uniform field is a fixed point of the diffusion solve when x0 = x
+      (beta = 1+4*alpha) up to rounding;
+    - Jacobi on the pressure system reduces the residual;
+    - after projection the divergence of (u,v) is smaller than before;
+    - advect with zero velocity is the identity on the interior."""
+    n = 4094
+    with F.FluidSolver(n) as s:
+        c = np.full((n + 2, n + 2), 0.375, np.float32)
+        s.upload(u=c, v=c)
+        a, b = F.coefficients(n, DT, DIFF)
+        s.diffuse(0, "u", "v", a, b, 40)
+        got = s.download("u")
+        assert np.abs(got - 0.375).max() <= 4e-7
+        rng = np.random.default_rng(0)
+        u, v = rnd(rng, n, 0, 1), rnd(rng, n, 0, 1)
+        s.upload(u=u, v=v)
+        s.set_bnd(1, "u")
+        s.set_bnd(2, "v")
+        s.computeDivergenceAndPressure("u", "v", "u_prev", "v_prev")
+        div0 = np.abs(s.download("v_prev")[1:-1, 1:-1]).max()
+        r0 = s.residual("u_prev", "v_prev", 1.0, 4.0)
+        s.diffuse(0, "u_prev", "v_prev", 1.0, 4.0, 40)
+        assert s.residual("u_prev", "v_prev", 1.0, 4.0) < r0
+        s.lastProject("u", "v", "u_prev")
+        s.computeDivergenceAndPressure("u", "v", "dens", "dens_prev")
+        div1 = np.abs(s.download("dens_prev")[1:-1, 1:-1]).max()
+        assert div1 < div0
+        s.fill("u", 0.0)
+        s.fill("v", 0.0)
+        d0 = rnd(rng, n)
+        s.upload(dens_prev=d0)
+        s.advect(0, "dens", "dens_prev", "u", "v", DT)
+        assert_bit_equal(s.download("dens")[1:-1, 1:-1], d0[1:-1, 1:-1], "zero-velocity advect")
+
+
+def test_variants_agree_at_4096(F, oracle):
+    """All three Jacobi kernels give the same bits on the bench workload, and
+    they match the oracle on a band of rows (full-size CPU solve is too slow)."""
+    n = 4094
+    rng = np.random.default_rng(3)
+    x, x0 = rnd(rng, n), rnd(rng, n)
+    outs = []
+    for variant in (0, 1, 2):
+        with F.FluidSolver(n, jacobi=variant) as s:
+            s.upload(u=x, v=x0)
+            s.diffuse(0, "u", "v", 1.0, 4.0, 4)
+            outs.append(s.download("u"))
+    assert_bit_equal(outs[1], outs[0], "LDS vs stream")
+    assert_bit_equal(outs[2], outs[0], "naive vs stream")
+    want = x.copy()
+    oracle.diffuse(0, want, x0, 1.0, 4.0, 4)
+    assert_bit_equal(outs[0], want, "stream vs oracle, 4 sweeps at 4096^2")
