@@ -71,6 +71,24 @@ def measure(solver, dist, world, steps, warmup, iters, cells):
     return elapsed, jac_ms, sweeps
 
 
+def pmc_traffic(kernel, grid):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
+    PMC summary (profiles/r*_<grid>_pmc.json, written by tools/summarize_profiles.py
+    from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this same command,
+    gfx950 x2 read correction applied).  None when no summary matches."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%d_pmc.json" % grid))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for name, v in d.items():
+            if name.split("<")[0] == kernel and v.get("hbm_bytes_per_launch"):
+                best = (v["hbm_bytes_per_launch"], os.path.basename(f))
+    return best
+
+
 def cpu_baseline(n, fields, iters):
     """The oracle leg (checker only): one full step and one 40-sweep pressure
     solve on ONE host core at the bench workload's N -- the reference itself
@@ -156,6 +174,10 @@ def main():
                      "note": "per GPU: 12 B/cell x %d cells/launch / mean launch time over %d timed launches (HIP events)"
                              % (cells // world, sweeps)},
     }
+    tr = pmc_traffic("k_jacobi_%s" % ["stream", "lds", "naive"][a.variant], grid) if world == 1 else None
+    if tr:
+        line["roofline"]["traffic"] = tr[0]
+        line["roofline"]["traffic_source"] = "profiles/" + tr[1]
     if calls:
         line["exchanges_per_rank"] = {"halo": calls[0], "gather": calls[1], "max": calls[2]}
     if world == 1 and not a.no_scaling_base and grid != 8192:

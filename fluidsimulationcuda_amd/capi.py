@@ -90,6 +90,13 @@ def lib():
         if not os.path.exists(LIB):
             raise ImportError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB)
+        try:
+            # torch wheels bundle their own libamdhip64/libhsa-runtime64; two HIP
+            # runtimes in one process cannot both own the GPU.  Loading torch
+            # first makes our DT_NEEDED libamdhip64.so.7 resolve to that copy.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB)
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)

@@ -1,0 +1,235 @@
+"""GPU: the row-slab (multi-GPU) orchestration on ONE device.  P contexts, one
+thread each, stand in for P ranks; the exchange callback is an in-process fake
+(device-to-device row copies between the contexts' arenas behind a thread
+barrier).  The bar is the multi-GPU contract of SURVEY.md 8(e): results
+bit-identical to the single-context run -- which test_gpu_step pins to the
+reference."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal, rnd
+
+pytestmark = pytest.mark.gpu
+DT, VISC, DIFF = 0.016, 0.0025, 0.1
+
+
+class FakeFabric:
+    """Shared state of the P fake ranks: a barrier and everyone's field tensors."""
+
+    def __init__(self, nranks):
+        self.nranks = nranks
+        self.barrier = threading.Barrier(nranks)
+        self.solvers = [None] * nranks
+        self.scalars = [0.0] * nranks
+        self.log = [[] for _ in range(nranks)]
+
+    def make_callback(self, rank):
+        import torch
+        from fluidsimulationcuda_amd import capi
+        from fluidsimulationcuda_amd.slab import slab_rows
+
+        def cb(kind, ids, depth, scalar):
+            me = self.solvers[rank]
+            self.log[rank].append((kind, tuple(ids), depth))
+            if kind == capi.XCHG_MAX:
+                self.scalars[rank] = scalar
+                self.barrier.wait()
+                out = max(self.scalars)
+                self.barrier.wait()
+                return out
+            torch.cuda.synchronize()
+            self.barrier.wait()                      # everyone's producers are done
+            lo, hi = me.owned_rows
+            for fid in ids:
+                mine = me.fields[fid]
+                if kind == capi.XCHG_HALO:
+                    if rank > 0:                     # pull the rows above my slab from the rank above
+                        mine[lo - depth:lo].copy_(self.solvers[rank - 1].fields[fid][lo - depth:lo])
+                    if rank < self.nranks - 1:
+                        mine[hi:hi + depth].copy_(self.solvers[rank + 1].fields[fid][hi:hi + depth])
+                else:                                # gather: pull every other slab (+ wall rows)
+                    for r in range(self.nranks):
+                        if r == rank:
+                            continue
+                        a, b = slab_rows(me.n, r, self.nranks)
+                        a -= 1 if r == 0 else 0
+                        b += 1 if r == self.nranks - 1 else 0
+                        mine[a:b].copy_(self.solvers[r].fields[fid][a:b])
+            torch.cuda.synchronize()
+            self.barrier.wait()                      # nobody overwrites rows still being read
+            return None
+
+        return cb
+
+
+def run_ranks(n, nranks, halo, fields, body, jacobi=0):
+    """Run body(solver) on every fake rank; returns the gathered fields."""
+    from fluidsimulationcuda_amd.slab import SlabSolver
+    fab = FakeFabric(nranks)
+    solvers = []
+    for r in range(nranks):
+        s = SlabSolver.__new__(SlabSolver)
+        _init_fake(s, n, r, nranks, halo, jacobi)
+        s.set_exchange(fab.make_callback(r))
+        fab.solvers[r] = s
+        s.load_global(**fields)
+        solvers.append(s)
+    errs = []
+
+    def work(r):
+        try:
+            body(solvers[r])
+            solvers[r].synchronize()
+        except Exception as e:      # noqa: BLE001
+            errs.append((r, e))
+            fab.barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    out = {}
+    for name in ("u", "v", "dens", "u_prev", "v_prev", "dens_prev"):
+        full = np.zeros((n + 2, n + 2), np.float32)
+        for s in solvers:
+            lo, hi = s.owned_rows
+            lo -= 1 if s.rank == 0 else 0
+            hi += 1 if s.rank == nranks - 1 else 0
+            s.download_rows(name, full, lo, hi)
+        out[name] = full
+    for s in solvers:
+        s.close()
+    return out, fab
+
+
+def _init_fake(s, n, rank, nranks, halo, jacobi):
+    """SlabSolver.__init__ minus the torch.distributed exchange."""
+    import ctypes as C
+    import torch
+    from fluidsimulationcuda_amd import capi
+    from fluidsimulationcuda_amd.solver import FluidSolver
+    L = capi.lib()
+    nbytes = L.fluid_arena_bytes(n)
+    pitch, xoff, ff = C.c_int(), C.c_int(), C.c_size_t()
+    capi.check(L.fluid_layout(n, C.byref(pitch), C.byref(xoff), C.byref(ff)))
+    s.pitch, s.xoff, s.device = pitch.value, xoff.value, torch.device("cuda", 0)
+    s.arena = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+    FluidSolver.__init__(s, n, rank=rank, nranks=nranks, halo=halo, jacobi=jacobi,
+                         stream=torch.cuda.current_stream().cuda_stream,
+                         arena_ptr=s.arena.data_ptr(), arena_bytes=nbytes)
+    s.fields = [s.arena[k * ff.value:(k + 1) * ff.value].view(n + 2, s.pitch) for k in range(capi.NFIELDS)]
+    s.exchange = None
+
+
+def single(n, fields, body):
+    import fluidsimulationcuda_amd as F
+    with F.FluidSolver(n) as s:
+        s.upload(**fields)
+        body(s)
+        return {k: s.download(k) for k in ("u", "v", "dens", "u_prev", "v_prev", "dens_prev")}
+
+
+def synthetic(n, seed=1):
+    from fluidsimulationcuda_amd.harness import initialize_parameters
+    return initialize_parameters(n, seed=seed)
+
+
+@pytest.mark.parametrize("n,nranks,halo", [(126, 2, 8), (126, 4, 3), (61, 3, 1), (257, 8, 5), (254, 2, 40),
+                                           (126, 2, 7)])
+def test_steps_bit_identical_to_one_gpu(n, nranks, halo):
+    """Three full steps: slabs == single context, every field, every bit
+    (includes uneven splits, halo depths that do / do not divide 40)."""
+    fields = synthetic(n)
+
+    def body(s):
+        s.step(1, use_sources=True)
+        s.step(2)
+
+    want = single(n, fields, body)
+    got, fab = run_ranks(n, nranks, halo, fields, body)
+    for k in ("u", "v", "dens"):
+        assert_bit_equal(got[k], want[k], "%s, %d slabs halo %d" % (k, nranks, halo))
+    from fluidsimulationcuda_amd import capi
+    kinds = [e[0] for e in fab.log[0]]
+    assert kinds.count(capi.XCHG_MAX) == 2 * 3            # two advect bounds per step
+    # deep ghost zones: far fewer halo exchanges than the 200 sweeps of a step
+    depth = max(1, min(halo, n // nranks - 1))
+    per_solve = 1 + (40 - 1) // depth
+    assert kinds.count(capi.XCHG_HALO) <= 3 * (5 * per_solve + 2 * 2 + 2 + 1)
+
+
+def test_advect_large_velocity_falls_back_to_gather():
+    """Back-trace longer than a neighbour's slab: the solver must gather whole
+    fields (FLUID_XCHG_GATHER) and still match one GPU bit for bit."""
+    n, nranks = 126, 4
+    rng = np.random.default_rng(11)
+    fields = dict(u=rnd(rng, n, -30, 30), v=rnd(rng, n, -30, 30), dens_prev=rnd(rng, n),
+                  dens=np.zeros((n + 2, n + 2), np.float32))
+
+    def body(s):
+        s.advect(0, "dens", "dens_prev", "u", "v", DT)
+
+    want = single(n, fields, body)
+    got, fab = run_ranks(n, nranks, 4, fields, body)
+    assert_bit_equal(got["dens"], want["dens"], "advect with gather fallback")
+    from fluidsimulationcuda_amd import capi
+    assert any(e[0] == capi.XCHG_GATHER for e in fab.log[0])
+
+
+def test_advect_small_velocity_uses_bounded_halo():
+    n, nranks = 254, 4
+    rng = np.random.default_rng(12)
+    fields = dict(u=rnd(rng, n, -0.5, 0.5), v=rnd(rng, n, -0.5, 0.5), dens_prev=rnd(rng, n),
+                  dens=np.zeros((n + 2, n + 2), np.float32))
+
+    def body(s):
+        s.advect(0, "dens", "dens_prev", "u", "v", DT)
+
+    want = single(n, fields, body)
+    got, fab = run_ranks(n, nranks, 4, fields, body)
+    assert_bit_equal(got["dens"], want["dens"], "advect with bounded halo")
+    from fluidsimulationcuda_amd import capi
+    halos = [e for e in fab.log[1] if e[0] == capi.XCHG_HALO]
+    # dt0*vmax = 0.016*254*0.5 ~ 2.03 -> ceil + 2 = 5 rows
+    assert len(halos) == 1 and halos[0][2] == 5 and not any(e[0] == capi.XCHG_GATHER for e in fab.log[1])
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_operators_on_slabs(variant):
+    n, nranks = 126, 3
+    rng = np.random.default_rng(13)
+    fields = dict(u=rnd(rng, n), v=rnd(rng, n), dens=rnd(rng, n), u_prev=rnd(rng, n), v_prev=rnd(rng, n),
+                  dens_prev=rnd(rng, n))
+
+    def body(s):
+        s.add_source("u", "u_prev", DT)
+        s.diffuse(1, "u_prev", "u", 0.3, 2.2, 6)
+        s.computeDivergenceAndPressure("u", "v", "dens", "dens_prev")
+        s.diffuse(0, "dens", "dens_prev", 1.0, 4.0, 10)
+        s.lastProject("u", "v", "dens")
+
+    want = single(n, fields, body)
+    got, _ = run_ranks(n, nranks, 4, fields, body, jacobi=variant)
+    for k in want:
+        assert_bit_equal(got[k], want[k], k)
+
+
+def test_too_many_slabs_is_rejected():
+    from fluidsimulationcuda_amd import capi
+    from fluidsimulationcuda_amd.solver import FluidSolver
+    with pytest.raises(capi.FluidError) as e:
+        FluidSolver(7, rank=0, nranks=4)
+    assert e.value.code == capi.E_INVALID
+    with pytest.raises(capi.FluidError):
+        FluidSolver(30, rank=2, nranks=2)
+
+
+def test_missing_exchange_callback_is_an_error():
+    from fluidsimulationcuda_amd import capi
+    from fluidsimulationcuda_amd.solver import FluidSolver
+    with FluidSolver(30, rank=0, nranks=2) as s:
+        with pytest.raises(capi.FluidError) as e:
+            s.step(1)
+        assert e.value.code == capi.E_COMM
