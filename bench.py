@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scaling-base", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured path) or gloo (host-staged rehearsal "
+                                                      "of the multi-process path when ranks outnumber GPUs)")
+    ap.add_argument("--check", action="store_true", help="multi-GPU: also verify bit equality with a 1-context run (small grids)")
     return ap.parse_args()
 
 
@@ -65,7 +68,8 @@ def measure(solver, dist, world, steps, warmup, iters, cells):
     solver.timing_enable(False)
     jac_ms, sweeps = t["jacobi_ms"], t["sweeps"]
     if world > 1:
-        buf = torch.tensor([elapsed, jac_ms], dtype=torch.float64, device="cuda")
+        buf = torch.tensor([elapsed, jac_ms], dtype=torch.float64,
+                           device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(buf, op=dist.ReduceOp.MAX)
         elapsed, jac_ms = float(buf[0]), float(buf[1])
     return elapsed, jac_ms, sweeps
@@ -131,10 +135,14 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
+    local = local % max(torch.cuda.device_count(), 1)       # rehearsal: several ranks may share a GPU
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.backend)
     from fluidsimulationcuda_amd.harness import initialize_parameters
     from fluidsimulationcuda_amd.slab import SlabSolver
 
@@ -151,6 +159,26 @@ def main():
         s.close()
         return out, fields, calls
 
+    if a.check and world > 1:
+        # rehearsal aid: W+K steps on slabs vs the same steps in one context on this rank's GPU
+        import fluidsimulationcuda_amd as F
+        fields = initialize_parameters(n, seed=a.seed)
+        s = SlabSolver(n, rank=rank, nranks=world, halo=a.halo, jacobi=a.variant)
+        s.load_global(**fields)
+        s.step(1, use_sources=True, iters=a.iters)
+        s.step(2, iters=a.iters)
+        got = {k: s.gather_global(k) for k in ("u", "v", "dens")}
+        s.close()
+        with F.FluidSolver(n) as one:
+            one.upload(**fields)
+            one.step(1, use_sources=True, iters=a.iters)
+            one.step(2, iters=a.iters)
+            for k in got:
+                same = np.array_equal(one.download(k).view(np.uint32), got[k].view(np.uint32))
+                if not same:
+                    sys.exit("rank %d: %s differs between %d slabs and one context" % (rank, k, world))
+        if rank == 0:
+            print("check ok: %d slabs bit-identical to one context at %dx%d" % (world, grid, grid), file=sys.stderr)
     (elapsed, jac_ms, sweeps), fields, calls = run(n, a.steps, a.warmup)
     ms_step = elapsed * 1e3 / a.steps
     t_sweep = jac_ms * 1e-3 / max(sweeps, 1)
@@ -164,7 +192,8 @@ def main():
         "config": {"workload": "%dx%d grid, full vel_step+dens_step, %d Jacobi sweeps/solve (200/step), fp32"
                                % (grid, grid, a.iters),
                    "grid": grid, "iters": a.iters, "jacobi_kernel": ["stream", "lds", "naive"][a.variant],
-                   "parallelism": "1 GPU" if world == 1 else "row slabs x%d, RCCL halo rows" % world},
+                   "parallelism": "1 GPU" if world == 1 else "row slabs x%d, %s halo rows" % (
+                       world, "RCCL" if a.backend == "nccl" else a.backend + " (host-staged rehearsal)")},
         "ms_per_sim_step": ms_step,
         "us_per_jacobi_sweep": t_sweep * 1e6,
         "step_algorithmic_GBps": BYTES_PER_CELL_STEP * cells / (ms_step * 1e-3) / 1e9,

@@ -35,15 +35,28 @@ class TorchExchange:
     `fields[id]` is a [n+2, pitch] tensor view of field `id`; rows of it are
     contiguous, so a halo needs no packing."""
 
-    def __init__(self, fields, n, rank, nranks, group=None):
+    def __init__(self, fields, n, rank, nranks, group=None, stream=None):
         self.fields, self.n, self.rank, self.nranks, self.group = fields, n, rank, nranks, group
+        self.stream = stream        # torch.cuda.Stream the solver's kernels run on (None: CPU tensors)
         self.lo, self.hi = slab_rows(n, rank, nranks)
         self.calls = {capi.XCHG_HALO: 0, capi.XCHG_GATHER: 0, capi.XCHG_MAX: 0}
+        # RCCL moves device memory directly.  gloo cannot, so device rows are
+        # staged through host buffers: used only to rehearse the multi-process
+        # path on a box with fewer GPUs than ranks (tests, bench --backend gloo).
+        self.staged = fields[0].is_cuda and dist.get_backend(group) != "nccl"
 
     def _peer(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
 
     def __call__(self, kind, ids, depth, scalar):
+        # collectives must order against the solver's kernels: make its stream
+        # torch's current stream for the duration of the exchange
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                return self._dispatch(kind, ids, depth, scalar)
+        return self._dispatch(kind, ids, depth, scalar)
+
+    def _dispatch(self, kind, ids, depth, scalar):
         self.calls[kind] += 1
         if kind == capi.XCHG_HALO:
             return self.halo(ids, depth)
@@ -57,20 +70,32 @@ class TorchExchange:
         lo, hi = self.lo, self.hi
         if depth < 1 or depth > hi - lo:
             raise ValueError("halo depth %d does not fit slab of %d rows" % (depth, hi - lo))
-        ops = []
+        ops, landing = [], []
+
+        def send(rows, peer):
+            ops.append(dist.P2POp(dist.isend, rows.cpu() if self.staged else rows, peer, self.group))
+
+        def recv(rows, peer):
+            buf = torch.empty(rows.shape, dtype=rows.dtype) if self.staged else rows
+            ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
+            if self.staged:
+                landing.append((rows, buf))
+
         for fid in ids:             # same order on every rank: sends and receives pair up
             f = self.fields[fid]
             if self.rank > 0:
                 up = self._peer(self.rank - 1)
-                ops.append(dist.P2POp(dist.isend, f[lo:lo + depth], up, self.group))
-                ops.append(dist.P2POp(dist.irecv, f[lo - depth:lo], up, self.group))
+                send(f[lo:lo + depth], up)
+                recv(f[lo - depth:lo], up)
             if self.rank < self.nranks - 1:
                 dn = self._peer(self.rank + 1)
-                ops.append(dist.P2POp(dist.isend, f[hi - depth:hi], dn, self.group))
-                ops.append(dist.P2POp(dist.irecv, f[hi:hi + depth], dn, self.group))
+                send(f[hi - depth:hi], dn)
+                recv(f[hi:hi + depth], dn)
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        for rows, buf in landing:
+            rows.copy_(buf)
 
     def gather(self, ids):
         for fid in ids:
@@ -79,10 +104,17 @@ class TorchExchange:
                 lo, hi = slab_rows(self.n, r, self.nranks)
                 lo -= 1 if r == 0 else 0                    # end slabs own the wall rows
                 hi += 1 if r == self.nranks - 1 else 0
-                dist.broadcast(f[lo:hi], src=self._peer(r), group=self.group)
+                if self.staged:
+                    buf = f[lo:hi].cpu()
+                    dist.broadcast(buf, src=self._peer(r), group=self.group)
+                    if r != self.rank:
+                        f[lo:hi].copy_(buf)
+                else:
+                    dist.broadcast(f[lo:hi], src=self._peer(r), group=self.group)
 
     def maximum(self, value):
-        t = torch.tensor([value], dtype=torch.float32, device=self.fields[0].device)
+        dev = "cpu" if self.staged else self.fields[0].device
+        t = torch.tensor([value], dtype=torch.float32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
@@ -112,14 +144,18 @@ class SlabSolver(FluidSolver):
         self.pitch, self.xoff = pitch.value, xoff.value
         with torch.cuda.device(self.device):
             self.arena = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.device)
-            stream = torch.cuda.current_stream().cuda_stream
-            super().__init__(n, rank=rank, nranks=nranks, halo=halo, jacobi=jacobi, stream=stream,
+            # a real (non-null) stream: handle 0 would mean "library-owned stream"
+            # to fluid_create_ex, and nothing would order RCCL against the kernels
+            self.torch_stream = torch.cuda.Stream(device=self.device)
+            torch.cuda.synchronize(self.device)        # the zero-fill ran on torch's default stream
+            super().__init__(n, rank=rank, nranks=nranks, halo=halo, jacobi=jacobi,
+                             stream=self.torch_stream.cuda_stream,
                              arena_ptr=self.arena.data_ptr(), arena_bytes=nbytes)
         self.fields = [self.arena[k * ff.value:(k + 1) * ff.value].view(n + 2, self.pitch)
                        for k in range(capi.NFIELDS)]
         self.exchange = None
         if nranks > 1:
-            self.exchange = TorchExchange(self.fields, n, rank, nranks, group)
+            self.exchange = TorchExchange(self.fields, n, rank, nranks, group, stream=self.torch_stream)
             self.set_exchange(self.exchange)
 
     def interior(self, field):
@@ -141,5 +177,7 @@ class SlabSolver(FluidSolver):
         an in-place all-gather of the slabs, then one download (bit preserving)."""
         fid = capi.FIELD_NAMES.index(field) if isinstance(field, str) else int(field)
         if self.nranks > 1:
-            self.exchange.gather([fid])
+            self.synchronize()
+            self.exchange(capi.XCHG_GATHER, [fid], 0, None)
+            torch.cuda.synchronize(self.device)
         return self.download(fid)

@@ -39,8 +39,8 @@ class FakeFabric:
                 out = max(self.scalars)
                 self.barrier.wait()
                 return out
-            torch.cuda.synchronize()
-            self.barrier.wait()                      # everyone's producers are done
+            me.synchronize()                         # this rank's producers are done
+            self.barrier.wait()                      # ... and so are everyone else's
             lo, hi = me.owned_rows
             for fid in ids:
                 mine = me.fields[fid]
@@ -116,8 +116,10 @@ def _init_fake(s, n, rank, nranks, halo, jacobi):
     capi.check(L.fluid_layout(n, C.byref(pitch), C.byref(xoff), C.byref(ff)))
     s.pitch, s.xoff, s.device = pitch.value, xoff.value, torch.device("cuda", 0)
     s.arena = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+    s.torch_stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
     FluidSolver.__init__(s, n, rank=rank, nranks=nranks, halo=halo, jacobi=jacobi,
-                         stream=torch.cuda.current_stream().cuda_stream,
+                         stream=s.torch_stream.cuda_stream,
                          arena_ptr=s.arena.data_ptr(), arena_bytes=nbytes)
     s.fields = [s.arena[k * ff.value:(k + 1) * ff.value].view(n + 2, s.pitch) for k in range(capi.NFIELDS)]
     s.exchange = None
