@@ -13,7 +13,8 @@ from ._build import LIB
 OK, E_INVALID, E_NOMEM, E_HIP, E_COMM = 0, 1, 2, 3, 4
 U, V, DENS, U_PREV, V_PREV, DENS_PREV, TMP0, TMP1, TMP2 = range(9)
 NFIELDS = 9
-JACOBI_STREAM, JACOBI_LDS, JACOBI_NAIVE = 0, 1, 2
+JACOBI_STREAM, JACOBI_LDS, JACOBI_NAIVE, JACOBI_TB = 0, 1, 2, 3
+PARAM_TB_MAX_SWEEPS, PARAM_TB_ROWS, PARAM_HALO, PARAM_TB_FAST_DIVISION = 0, 1, 2, 3
 XCHG_HALO, XCHG_GATHER, XCHG_MAX = 0, 1, 2
 FIELD_NAMES = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev", "tmp0", "tmp1", "tmp2")
 
@@ -73,6 +74,7 @@ SIGNATURES = {
     "fluid_residual": [_ctx, _i, _i, _f, _f, C.POINTER(_f)],
     "fluid_absmax_velocity": [_ctx, _i, _i, C.POINTER(_f)],
     "fluid_set_jacobi_variant": [_ctx, _i],
+    "fluid_set_param": [_ctx, _i, _i],
     "fluid_timing_enable": [_ctx, _i],
     "fluid_timing_read": [_ctx, C.POINTER(Timing), _i],
     "fluid_set_exchange": [_ctx, EXCHANGE_FN, C.c_void_p],

@@ -7,7 +7,7 @@ namespace fluid {
 // column c of a device row lives at float index c + XOFF (column 1 => 256-B line start)
 constexpr int XOFF = 63;
 
-enum JacobiVariant { JACOBI_STREAM = 0, JACOBI_LDS = 1, JACOBI_NAIVE = 2, JACOBI_VARIANTS = 3 };
+enum JacobiVariant { JACOBI_STREAM = 0, JACOBI_LDS = 1, JACOBI_NAIVE = 2, JACOBI_TB = 3, JACOBI_VARIANTS = 4 };
 
 // pitch (floats) for interior size n: room for XOFF, ceil(n/4) float4s and the
 // right ghost, rounded to a 256-byte multiple.
@@ -17,6 +17,9 @@ void launch_set_bnd(hipStream_t s, float* f, int pitch, int n, int b);
 void launch_add_source(hipStream_t s, float* x, const float* src, int pitch, int row_lo, int row_hi, float dt);
 void launch_jacobi(hipStream_t s, int variant, const float* x, const float* x0, float* out, int pitch, int n,
                    int row_lo, int row_hi, float alpha, float beta, int b);
+void launch_jacobi_tb(hipStream_t s, int T, int divmode, const float* x, const float* x0, float* out, int pitch,
+                      int n, int row_lo, int row_hi, int rb, float alpha, float beta, double yd, int b);
+void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, double yd, unsigned long long* bad);
 void launch_advect(hipStream_t s, float* d, const float* d0, const float* u, const float* v, int pitch, int n,
                    int row_lo, int row_hi, float dt0, int b);
 void launch_divergence(hipStream_t s, const float* u, const float* v, float* p, float* div, int pitch, int n,

@@ -45,6 +45,17 @@ __device__ __forceinline__ float from_lane_above(float v, float edge)
     return __int_as_float(r);
 }
 
+// Same shifts with bound_ctrl: lane 0 / 63 read 0.  No `old` operand to set up,
+// so the compiler folds the shift into the consuming add (v_add_f32_dpp).
+__device__ __forceinline__ float lane_below0(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_above0(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
 // Ghost cells that derive from interior cell (j,i) holding `val`
 // (FluidSequential.c:65-74): across a vertical wall the ghost is -val when
 // b==1, across a horizontal wall -val when b==2, else a copy; a corner is
@@ -280,6 +291,296 @@ __global__ __launch_bounds__(256) void k_jacobi_stream(const float* __restrict__
     }
 }
 
+// (iv) temporally blocked: T sweeps per launch, results identical to T launches
+// of any variant above (the only way past 12 B/cell/sweep).
+//
+// One wave = one window of 64 float4 lanes (256 columns) x one strip of `rb`
+// output rows, marching down the rows with all T sweeps in flight: at step t it
+// loads row t of x and x0 and, for s = 1..T, produces row t-s of "x after s
+// sweeps" from the three rows of stage s-1 it still holds.  Everything lives in
+// registers: per stage a three-row ring of its input, and a queue of the last T
+// x0 rows.  The time loop is unrolled by three so the rings rotate by renaming,
+// not by moving.  Left/right neighbours come from the adjacent lanes by DPP; a
+// wave has no one to ask at its two ends, so windows overlap by HL = ceil(T/4)
+// lanes per side and only the inner 64-2*HL lanes store (the wrong values creep
+// inwards one column per sweep and never reach them).  Strips overlap by T rows
+// per side the same way.  No LDS, no barriers.
+//
+// set_bnd is replayed inside the pipeline (it must be: sweep s+1 reads the
+// ghosts of sweep s): the lanes holding ghost column 0 / n+1 overwrite that
+// component from the neighbouring interior column after every stage (EDGE
+// windows only), and ghost rows 0 / n+1 of a stage are the flipped rows 1 / n
+// of the same stage (steps near a wall take the `general` path; all others a
+// branch-free body).  Domain walls do not shrink the valid region.  Corner
+// ghosts are never read by a 5-point stencil, so they are only formed in the
+// final store.  Negation is a sign-bit XOR (bit-identical to the reference's
+// unary minus, zeros and NaNs included).
+//
+// DIVMODE 0: (..)/beta, true division (about 20 VALU-op times on gfx950).
+// DIVMODE 1: beta is a power of two and `beta` carries its exact reciprocal:
+//   (..)*rbeta is the same correctly rounded result for every input (pressure
+//   solve: beta = 4).
+// DIVMODE 2: (float)((double)(..) * yd) with yd = RN64(1/beta).  The double
+//   product is within 2^-52 relative of the true quotient, while a quotient of two
+//   floats is never that close to a float rounding boundary (the boundary would
+//   need an odd 25-bit significand times beta's to fit 24 bits), so the final
+//   conversion rounds exactly as IEEE division does; zeros, denormals, inf and NaN
+//   need no special case.  The one exception class -- quotients that land exactly
+//   on a denormal midpoint, possible for a few even-integer-like beta -- is why
+//   the solver proves each beta on the device before using this mode:
+//   k_validate_div compares it with a/beta for all 2^32 inputs (about 6 op times).
+struct TbArgs {
+    const float* xc;      // x   + column offset of this lane
+    const float* rc;      // x0  + column offset
+    float* oc;            // out + column offset
+    size_t P;
+    int n, q_lo, q_hi, t_ld, cg, last;
+    float alpha, beta;
+    double yd;            // DIVMODE 2: 1/beta rounded to double
+    unsigned sx, sy;      // sign masks: flip across vertical / horizontal walls
+    bool ld_ok, own, st_int, st_rg, is_lg, is_rg, left_edge, right_edge;
+};
+
+__device__ __forceinline__ float fxor(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) ^ m); }
+__device__ __forceinline__ float4 fxor4(const float4& v, unsigned m)
+{
+    return make_float4(fxor(v.x, m), fxor(v.y, m), fxor(v.z, m), fxor(v.w, m));
+}
+
+template <int DIVMODE>
+__device__ __forceinline__ float tb_div(float num, float beta, double yd)
+{
+    if (DIVMODE == 0) return num / beta;
+    if (DIVMODE == 1) return num * beta;           // beta holds the exact reciprocal
+    return (float)((double)num * yd);
+}
+
+template <int DIVMODE>
+__device__ __forceinline__ float4 tb_stencil(const float4& up, const float4& me, const float4& dn, const float4& r,
+                                             float alpha, float beta, double yd)
+{
+    float4 G;
+    float nb;
+    nb = lane_below0(me.w) + me.y; nb = nb + up.x; nb = nb + dn.x; G.x = tb_div<DIVMODE>(r.x + alpha * nb, beta, yd);
+    nb = me.x + me.z;              nb = nb + up.y; nb = nb + dn.y; G.y = tb_div<DIVMODE>(r.y + alpha * nb, beta, yd);
+    nb = me.y + me.w;              nb = nb + up.z; nb = nb + dn.z; G.z = tb_div<DIVMODE>(r.z + alpha * nb, beta, yd);
+    nb = me.z + lane_above0(me.x); nb = nb + up.w; nb = nb + dn.w; G.w = tb_div<DIVMODE>(r.w + alpha * nb, beta, yd);
+    return G;
+}
+
+// All 2^32 float bit patterns a: does tb_div<DIVMODE>(a) equal a / beta bit for bit
+// (any NaN matches any NaN)?  Counts mismatches; the solver requires zero.
+template <int DIVMODE>
+__global__ __launch_bounds__(256) void k_validate_div(float beta, float arg, double yd, unsigned long long* __restrict__ bad)
+{
+    unsigned long long n = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x; k < (1ull << 32); k += stride) {
+        const float a = __uint_as_float((unsigned)k);
+        const float ref = a / beta;
+        const float got = tb_div<DIVMODE>(a, arg, yd);
+        n += (ref != ref) ? !(got != got) : (__float_as_uint(got) != __float_as_uint(ref));
+    }
+    if (n) atomicAdd(bad, n);
+}
+
+// ghost columns of one freshly computed row (set_bnd, FluidSequential.c:65-66);
+// v1 / vn return column 1 / column n of the row (for the corners).
+__device__ __forceinline__ void tb_fix_columns(float4& G, const TbArgs& a, float& v1, float& vn)
+{
+    if (a.left_edge) {
+        v1 = lane_above0(G.x);
+        if (a.is_lg) G.w = fxor(v1, a.sx);
+    }
+    if (a.right_edge) {
+        if (a.cg == 0) {
+            vn = lane_below0(G.w);
+            if (a.is_rg) G.x = fxor(vn, a.sx);
+        } else if (a.cg == 1) { vn = G.x; if (a.is_rg) G.y = fxor(vn, a.sx);
+        } else if (a.cg == 2) { vn = G.y; if (a.is_rg) G.z = fxor(vn, a.sx);
+        } else                { vn = G.z; if (a.is_rg) G.w = fxor(vn, a.sx); }
+    }
+}
+
+// final stage: store row q, its ghost columns, and ghost rows / corners
+template <bool EDGE>
+__device__ __forceinline__ void tb_store(const float4& G, int q, const TbArgs& a, float v1, float vn)
+{
+    const bool top = (q == 1), bot = (q == a.n);
+    const float4 g4 = fxor4(G, a.sy);
+    if (!EDGE) {
+        if (a.own) {
+            *reinterpret_cast<float4*>(a.oc + (size_t)q * a.P) = G;
+            if (top) *reinterpret_cast<float4*>(a.oc) = g4;
+            if (bot) *reinterpret_cast<float4*>(a.oc + (size_t)(a.n + 1) * a.P) = g4;
+        }
+        return;
+    }
+    if (a.st_int) {
+#pragma unroll
+        for (int side = 0; side < 3; ++side) {
+            if (side == 1 && !top) continue;
+            if (side == 2 && !bot) continue;
+            float* o = a.oc + (side == 0 ? (size_t)q : side == 1 ? (size_t)0 : (size_t)(a.n + 1)) * a.P;
+            const float4 val = side == 0 ? G : g4;
+            if (a.last >= 3) {
+                *reinterpret_cast<float4*>(o) = val;
+            } else {
+                o[0] = val.x;
+                if (a.last >= 1) o[1] = val.y;
+                if (a.last >= 2) o[2] = val.z;
+            }
+        }
+    }
+    if (a.is_lg) {                       // ghost column 0 (+ corners): only window 0 has k == -1
+        a.oc[(size_t)q * a.P + 3] = G.w;
+        const float corner = 0.5f * (fxor(v1, a.sy) + fxor(v1, a.sx));
+        if (top) a.oc[3] = corner;
+        if (bot) a.oc[(size_t)(a.n + 1) * a.P + 3] = corner;
+    }
+    if (a.st_rg) {                       // ghost column n+1 (+ corners)
+        const float gv = a.cg == 0 ? G.x : a.cg == 1 ? G.y : a.cg == 2 ? G.z : G.w;
+        a.oc[(size_t)q * a.P + a.cg] = gv;
+        const float corner = 0.5f * (fxor(vn, a.sy) + fxor(vn, a.sx));
+        if (top) a.oc[a.cg] = corner;
+        if (bot) a.oc[(size_t)(a.n + 1) * a.P + a.cg] = corner;
+    }
+}
+
+// x0 queue shift as straight-line code (a loop here is recognised as memmove,
+// which pins the whole queue in scratch memory).
+template <int S, int N>
+__device__ __forceinline__ void tb_qshift(float4 (&Q)[N])
+{
+    if constexpr (S >= 1) {
+        Q[S] = Q[S - 1];
+        tb_qshift<S - 1, N>(Q);
+    }
+}
+
+// One time step.  Ring s (s = 0..T-1) holds three consecutive rows of "x after
+// s sweeps"; at phase PH its slots are up = PH, me = PH+1, fresh = PH+2 (mod 3).
+// WALL = false: the strip is far enough from rows 0 / n+1 that every row a later
+// stage needs is interior -- a branch-free body.  WALL = true: per-stage checks,
+// ghost rows of each stage regenerated from its rows 1 / n.
+template <int T, int DIVMODE, bool EDGE, bool WALL, int PH>
+__device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T + 1], float4& nx, float4& nq,
+                                        const TbArgs& a)
+{
+    constexpr int UP = PH % 3, ME = (PH + 1) % 3, FR = (PH + 2) % 3;
+    W[0][FR] = nx;                                       // stage 0: row t of x
+    Q[0] = nq;
+    if (t < a.t_ld && a.ld_ok) {                         // prefetch row t+1 under this step's arithmetic
+        nx = *reinterpret_cast<const float4*>(a.xc + (size_t)(t + 1) * a.P);
+        nq = *reinterpret_cast<const float4*>(a.rc + (size_t)(t + 1) * a.P);
+    }
+#pragma unroll
+    for (int s = 1; s <= T; ++s) {
+        const int q = t - s;                             // row this stage produces now (wave-uniform)
+        if (!WALL) {
+            float4 G = tb_stencil<DIVMODE>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.beta, a.yd);
+            float v1 = 0.f, vn = 0.f;
+            if (EDGE) tb_fix_columns(G, a, v1, vn);
+            if (s < T) W[s][FR] = G;
+            else if (q >= a.q_lo && q < a.q_hi) tb_store<EDGE>(G, q, a, v1, vn);
+        } else {
+            // ring writes stay unconditional (selected values), so the rings stay in registers
+            const bool interior = (q >= 1 && q <= a.n);
+            float4 G = tb_stencil<DIVMODE>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.beta, a.yd);
+            float v1 = 0.f, vn = 0.f;
+            if (EDGE) tb_fix_columns(G, a, v1, vn);
+            if (s < T) {
+                const float4 me = W[s][ME];
+                const float4 flipped_me = fxor4(me, a.sy);   // ghost row n+1 of this stage = flipped row n
+                const float4 flipped_g = fxor4(G, a.sy);     // ghost row 0 of this stage = flipped row 1
+                const bool bot_ghost = (q == a.n + 1), top_ghost = (q == 1);
+                W[s][FR] = make_float4(bot_ghost ? flipped_me.x : G.x, bot_ghost ? flipped_me.y : G.y,
+                                       bot_ghost ? flipped_me.z : G.z, bot_ghost ? flipped_me.w : G.w);
+                W[s][ME] = make_float4(top_ghost ? flipped_g.x : me.x, top_ghost ? flipped_g.y : me.y,
+                                       top_ghost ? flipped_g.z : me.z, top_ghost ? flipped_g.w : me.w);
+            } else if (interior && q >= a.q_lo && q < a.q_hi) {
+                tb_store<EDGE>(G, q, a, v1, vn);
+            }
+        }
+    }
+    tb_qshift<T, T + 1>(Q);
+}
+
+template <int T, int DIVMODE, bool EDGE, bool WALL>
+__device__ __forceinline__ void tb_march(int t0, int t1, float4 nx, float4 nq, const TbArgs& a)
+{
+    float4 W[T][3], Q[T + 1];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < T; ++s) { W[s][0] = zero4; W[s][1] = zero4; W[s][2] = zero4; }
+#pragma unroll
+    for (int s = 0; s <= T; ++s) Q[s] = zero4;
+    // whole triples only: up to two surplus steps load nothing (t >= t_ld) and store nothing (q >= q_hi)
+    for (int t = t0; t <= t1; t += 3) {
+        tb_step<T, DIVMODE, EDGE, WALL, 0>(t, W, Q, nx, nq, a);
+        tb_step<T, DIVMODE, EDGE, WALL, 1>(t + 1, W, Q, nx, nq, a);
+        tb_step<T, DIVMODE, EDGE, WALL, 2>(t + 2, W, Q, nx, nq, a);
+    }
+}
+
+// second launch-bound argument = waves per SIMD the register allocator must leave room for
+template <int T, int DIVMODE>
+__global__ __launch_bounds__(256, (T <= 4 ? 4 : 2)) void k_jacobi_tb(const float* __restrict__ x, const float* __restrict__ x0,
+                                                   float* __restrict__ out, int pitch, int n, int row_lo,
+                                                   int row_hi, int rb, float alpha, float beta, double yd, int b)
+{
+    constexpr int HL = (T + 3) / 4;
+    constexpr int VS = 64 - 2 * HL;
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.y * 4 + (threadIdx.x >> 6);
+    TbArgs a;
+    a.yd = yd;
+    a.q_lo = row_lo + strip * rb;                        // this wave's output rows [q_lo, q_hi)
+    if (a.q_lo >= row_hi) return;                        // wave-uniform
+    a.q_hi = min(a.q_lo + rb, row_hi);
+    const int win = blockIdx.x;
+    const int k = win * VS - HL + lane;                  // float4 index: columns 1+4k .. 4+4k
+    const int nvec = (n + 3) >> 2;
+    a.ld_ok = k <= (pitch >> 2) - 17;                    // k >= -HL >= -16 always
+    a.P = (size_t)pitch;
+    const ptrdiff_t cofs = (ptrdiff_t)(XOFF + 1) + 4 * (ptrdiff_t)(a.ld_ok ? k : 0);
+    a.xc = x + cofs;
+    a.rc = x0 + cofs;
+    a.oc = out + cofs;
+    a.n = n;
+    const int kg = n >> 2;                               // ghost column n+1 = component cg of vector kg
+    a.cg = n & 3;
+    a.left_edge = (win == 0);                                                  // wave-uniform
+    a.right_edge = (kg >= win * VS - HL) && (kg < win * VS - HL + 64);         // wave-uniform
+    a.is_lg = (k == -1);
+    a.is_rg = (k == kg);
+    a.own = (lane >= HL) && (lane < 64 - HL);
+    a.st_int = a.own && k >= 0 && k < nvec;              // stores interior columns
+    a.st_rg = a.is_rg && (a.own || k == nvec);           // stores ghost column n+1 (exactly one lane grid-wide)
+    a.last = n - (1 + 4 * k);                            // component of column n in this lane (if 0..3)
+    a.sx = (b == 1) ? 0x80000000u : 0u;
+    a.sy = (b == 2) ? 0x80000000u : 0u;
+    a.alpha = alpha;
+    a.beta = beta;
+    const int t0 = max(0, a.q_lo - T), t1 = a.q_hi - 1 + T;
+    a.t_ld = min(t1, n + 1);                             // last row that exists
+    float4 nx = make_float4(0.f, 0.f, 0.f, 0.f), nq = nx;
+    if (a.ld_ok) {
+        nx = *reinterpret_cast<const float4*>(a.xc + (size_t)t0 * a.P);
+        nq = *reinterpret_cast<const float4*>(a.rc + (size_t)t0 * a.P);
+    }
+    // a strip whose input rows [q_lo-T, q_hi-1+T] all exist never needs a regenerated ghost row
+    const bool wall = (a.q_lo < T) || (a.q_hi - 1 + T > n + 1);      // wave-uniform
+    const bool edge = a.left_edge || a.right_edge;                   // wave-uniform
+    if (edge) {
+        if (wall) tb_march<T, DIVMODE, true, true>(t0, t1, nx, nq, a);
+        else      tb_march<T, DIVMODE, true, false>(t0, t1, nx, nq, a);
+    } else {
+        if (wall) tb_march<T, DIVMODE, false, true>(t0, t1, nx, nq, a);
+        else      tb_march<T, DIVMODE, false, false>(t0, t1, nx, nq, a);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // a5  advect (FluidSequential.c:107-141): one thread per cell; the wave reads
 // 64 consecutive u,v (coalesced) and gathers the four bilinear taps of d0.
@@ -444,6 +745,35 @@ void launch_jacobi(hipStream_t s, int variant, const float* x, const float* x0, 
                            pitch, n, row_lo, row_hi, alpha, beta, b);
     }
     }
+}
+
+// T in {8,4,2}.  divmode 0: beta; 1: beta = exact reciprocal; 2: beta unused, yd = RN64(1/beta).
+void launch_jacobi_tb(hipStream_t s, int T, int divmode, const float* x, const float* x0, float* out, int pitch,
+                      int n, int row_lo, int row_hi, int rb, float alpha, float beta, double yd, int b)
+{
+    const int rows = row_hi - row_lo;
+    if (rows <= 0) return;
+    const int HL = (T + 3) / 4, VS = 64 - 2 * HL;
+    const unsigned nvec = (n + 3) / 4;
+    const dim3 grid(cdiv(nvec, VS), cdiv(cdiv(rows, rb), 4)), block(256);
+#define FLUID_TB1(TT, DD) \
+    hipLaunchKernelGGL((k_jacobi_tb<TT, DD>), grid, block, 0, s, x, x0, out, pitch, n, row_lo, row_hi, rb, alpha, beta, yd, b)
+#define FLUID_TB(TT)                     \
+    if (divmode == 2) FLUID_TB1(TT, 2);  \
+    else if (divmode == 1) FLUID_TB1(TT, 1); \
+    else FLUID_TB1(TT, 0)
+    if (T == 8) { FLUID_TB(8); }
+    else if (T == 4) { FLUID_TB(4); }
+    else { FLUID_TB(2); }
+#undef FLUID_TB
+#undef FLUID_TB1
+}
+
+// mismatches of division mode `divmode` against a/beta over all 2^32 inputs are added to *bad
+void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, double yd, unsigned long long* bad)
+{
+    if (divmode == 1) hipLaunchKernelGGL((k_validate_div<1>), dim3(8192), dim3(256), 0, s, beta, arg, yd, bad);
+    else hipLaunchKernelGGL((k_validate_div<2>), dim3(8192), dim3(256), 0, s, beta, arg, yd, bad);
 }
 
 void launch_advect(hipStream_t s, float* d, const float* d0, const float* u, const float* v, int pitch, int n,

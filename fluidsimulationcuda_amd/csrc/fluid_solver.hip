@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/fluid_amd.h"
@@ -60,7 +61,10 @@ struct fluid_ctx {
     float* f[FLUID_NFIELDS] = {};
     unsigned int* d_scalar = nullptr;     // device word for the reductions
     unsigned int* h_scalar = nullptr;     // pinned host mirror
-    int variant = fluid::JACOBI_STREAM;
+    int variant = fluid::JACOBI_TB;
+    int tb_max_t = 8, tb_rows = 0, num_cu = 256;   // temporal blocking: sweeps/launch cap, rows/strip (0 = auto)
+    bool fast_div = true;                          // allow division modes 1/2 (each beta proven on the device first)
+    std::unordered_map<unsigned, int> div_mode;    // beta bits -> proven division mode
     // slab decomposition
     int rank = 0, nranks = 1, own0 = 1, own1 = 1, min_slab = 0, halo = 1;
     fluid_exchange_fn xchg = nullptr;
@@ -158,6 +162,41 @@ int timing_collect(fluid_ctx* c)
     return FLUID_OK;
 }
 
+// Division mode for `beta` in the temporally blocked kernel: 0 = true division,
+// 1 = multiply by the exact reciprocal (beta a power of two), 2 = f64 reciprocal
+// multiply.  Modes 1 and 2 are only used after k_validate_div has compared them
+// with a/beta for every one of the 2^32 float inputs on this device (a few ms,
+// once per beta and context).
+int division_mode(fluid_ctx* c, float beta, float* arg, double* yd)
+{
+    *arg = beta;
+    *yd = 1.0 / (double)beta;
+    if (!c->fast_div || !(beta > 0.f) || !std::isfinite(beta)) return 0;
+    unsigned bits;
+    std::memcpy(&bits, &beta, sizeof bits);
+    int e2 = 0;
+    const float rbeta = 1.0f / beta;
+    const bool pow2 = std::frexp(beta, &e2) == 0.5f && std::isnormal(rbeta) && rbeta * beta == 1.0f;
+    auto it = c->div_mode.find(bits);
+    int mode;
+    if (it != c->div_mode.end()) {
+        mode = it->second;
+    } else {
+        mode = pow2 ? 1 : 2;
+        unsigned long long* bad = reinterpret_cast<unsigned long long*>(c->d_scalar) + 1;   // 8-byte slot of the 256-B block
+        unsigned long long* hbad = reinterpret_cast<unsigned long long*>(c->h_scalar) + 1;
+        if (hipMemsetAsync(bad, 0, sizeof *bad, c->stream) != hipSuccess) return 0;
+        fluid::launch_validate_div(c->stream, mode, beta, pow2 ? rbeta : beta, *yd, bad);
+        if (hipMemcpyAsync(hbad, bad, sizeof *bad, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            return 0;
+        if (*hbad != 0) mode = 0;                  // never observed; keeps the bit-exact contract regardless
+        c->div_mode.emplace(bits, mode);
+    }
+    if (mode == 1) *arg = rbeta;
+    return mode;
+}
+
 // ---- operators on the owned slab -----------------------------------------------
 int op_add_source(fluid_ctx* c, int x, int s, float dt)
 {
@@ -165,10 +204,13 @@ int op_add_source(fluid_ctx* c, int x, int s, float dt)
     return FLUID_OK;
 }
 
-// FluidSequential.c:85-104.  Result lands in field x (iters even).  With
-// several slabs the ghost zone is `halo` rows deep: one exchange, then `halo`
-// sweeps over a range that shrinks by one row per sweep on each inner edge --
-// the same arithmetic per cell as the 1-GPU run, so results are bit-identical.
+// FluidSequential.c:85-104.  Result lands in field x.  With several slabs the
+// ghost zone is `halo` rows deep: one exchange, then `halo` sweeps over a range
+// that shrinks by one row per sweep on each inner edge -- the same arithmetic
+// per cell as the 1-GPU run, so results are bit-identical.  The temporally
+// blocked kernel runs T of those sweeps per launch.  Sweeps ping-pong between
+// x's buffer and TMP0's; if the result ends in TMP0's buffer the two fields
+// trade buffers (pointer swap, no copy) -- field ids, not addresses, are stable.
 int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int iters)
 {
     if (iters < 0 || (iters & 1)) return fail(FLUID_E_INVALID, "sweep count must be even and >= 0 (got %d)", iters);
@@ -177,21 +219,47 @@ int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int 
     if (iters == 0) return FLUID_OK;
     hipEvent_t stop;
     TRY(timing_begin(c, &stop));
-    float* cur = c->f[x];
-    float* nxt = c->f[FLUID_TMP0];
-    int cur_id = x, nxt_id = FLUID_TMP0;
-    const int H = c->nranks > 1 ? c->halo : 1;
-    if (c->nranks > 1) TRY(exchange(c, FLUID_XCHG_HALO, {x, x0}, H));
-    for (int k = 0; k < iters; ++k) {
+    int cur = x, nxt = FLUID_TMP0;
+    const bool multi = c->nranks > 1;
+    const int H = multi ? c->halo : iters;
+    float div_arg = beta;
+    double yd = 0.0;
+    const int divmode = c->variant == fluid::JACOBI_TB ? division_mode(c, beta, &div_arg, &yd) : 0;
+    if (multi) TRY(exchange(c, FLUID_XCHG_HALO, {x, x0}, H));
+    for (int k = 0; k < iters;) {
         const int s = k % H;
-        if (c->nranks > 1 && s == 0 && k > 0) TRY(exchange(c, FLUID_XCHG_HALO, {cur_id}, H));
-        const int reach = H - 1 - s;
+        if (multi && s == 0 && k > 0) TRY(exchange(c, FLUID_XCHG_HALO, {cur}, H));
+        int T = 1;
+        if (c->variant == fluid::JACOBI_TB) {
+            const int room = std::min(H - s, iters - k);
+            T = (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
+        }
+        const int reach = multi ? H - s - T : 0;
         const int lo = std::max(1, c->own0 - reach), hi = std::min(c->n + 1, c->own1 + reach);
-        fluid::launch_jacobi(c->stream, c->variant, cur, c->f[x0], nxt, c->pitch, c->n, lo, hi, alpha, beta, b);
+        if (T == 1) {
+            const int v = c->variant == fluid::JACOBI_TB ? fluid::JACOBI_STREAM : c->variant;
+            fluid::launch_jacobi(c->stream, v, c->f[cur], c->f[x0], c->f[nxt], c->pitch, c->n, lo, hi, alpha, beta, b);
+        } else {
+            int rb = c->tb_rows;
+            if (rb <= 0) {
+                // auto (tools/tb_sweep.py on MI355X, 4096^2 and 8192^2): the register-heavy T=8 kernel
+                // holds 2 waves per SIMD and likes one full round of them; T<=4 holds 4 and peaks
+                // near 2.8.  Longer strips amortise the 2T-row pipeline fill, shorter ones feed more
+                // SIMDs; past ~80-96 rows the fill is already < 20 % and more strips win.
+                const int HL = (T + 3) / 4, VS = 64 - 2 * HL;
+                const long long windows = ((c->n + 3) / 4 + VS - 1) / VS;
+                const long long want = (long long)c->num_cu * 4 * (T >= 8 ? 19 : 28) / 10;
+                rb = (int)(((long long)(hi - lo) * windows + want - 1) / want);
+                rb = std::max(2 * T, std::min(rb, T >= 8 ? 80 : 96));
+            }
+            fluid::launch_jacobi_tb(c->stream, T, divmode, c->f[cur], c->f[x0], c->f[nxt], c->pitch, c->n, lo, hi, rb,
+                                    alpha, div_arg, yd, b);
+        }
         std::swap(cur, nxt);
-        std::swap(cur_id, nxt_id);
+        k += T;
     }
     HIP_TRY(hipGetLastError());
+    if (cur != x) std::swap(c->f[x], c->f[FLUID_TMP0]);
     return timing_end(c, stop, iters);
 }
 
@@ -403,6 +471,12 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
         rc = fail(e == hipErrorOutOfMemory ? FLUID_E_NOMEM : FLUID_E_HIP, "%s: %s", what, hipGetErrorString(e));
         return false;
     };
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            c->num_cu = cus;
+    }
     if (!hip_ok(hipMemsetAsync(c->arena, 0, bytes, c->stream), "hipMemsetAsync(arena)")) return bail(rc);
     if (!hip_ok(hipMalloc((void**)&c->d_scalar, 256), "hipMalloc(scalar)")) return bail(rc);
     if (!hip_ok(hipHostMalloc((void**)&c->h_scalar, 256, hipHostMallocDefault), "hipHostMalloc")) return bail(rc);
@@ -417,6 +491,7 @@ int fluid_create(int N, fluid_ctx** out)
     std::memset(&cfg, 0, sizeof cfg);
     cfg.n = N;
     cfg.nranks = 1;
+    cfg.jacobi_variant = FLUID_JACOBI_TB;
     return fluid_create_ex(&cfg, out);
 }
 
@@ -509,6 +584,30 @@ int fluid_set_jacobi_variant(fluid_ctx* c, int variant)
     return FLUID_OK;
 }
 
+int fluid_set_param(fluid_ctx* c, int key, int value)
+{
+    TRY(check_ctx(c));
+    switch (key) {
+    case FLUID_PARAM_TB_MAX_SWEEPS:
+        if (value != 8 && value != 4 && value != 2) return fail(FLUID_E_INVALID, "TB_MAX_SWEEPS must be 8, 4 or 2");
+        c->tb_max_t = value;
+        return FLUID_OK;
+    case FLUID_PARAM_TB_ROWS:
+        if (value < 0) return fail(FLUID_E_INVALID, "TB_ROWS must be >= 0");
+        c->tb_rows = value;
+        return FLUID_OK;
+    case FLUID_PARAM_TB_FAST_DIVISION:
+        c->fast_div = value != 0;
+        return FLUID_OK;
+    case FLUID_PARAM_HALO:
+        if (value < 1) return fail(FLUID_E_INVALID, "HALO must be >= 1");
+        c->halo = c->nranks > 1 ? std::max(1, std::min(value, c->min_slab - 1)) : 1;
+        return FLUID_OK;
+    default:
+        return fail(FLUID_E_INVALID, "unknown parameter %d", key);
+    }
+}
+
 int fluid_set_exchange(fluid_ctx* c, fluid_exchange_fn fn, void* user)
 {
     TRY(check_ctx(c));
@@ -578,7 +677,8 @@ int fluid_op_jacobi_sweep(fluid_ctx* c, int b, int x, int x0, int out, float alp
     if (b < 0 || b > 2) return fail(FLUID_E_INVALID, "b must be 0, 1 or 2");
     if (out == x || out == x0) return fail(FLUID_E_INVALID, "jacobi_sweep: out must not alias an input");
     TRY(exchange(c, FLUID_XCHG_HALO, {x}, 1));
-    fluid::launch_jacobi(c->stream, c->variant, c->f[x], c->f[x0], c->f[out], c->pitch, c->n, c->own0, c->own1, alpha, beta, b);
+    const int v1 = c->variant == fluid::JACOBI_TB ? fluid::JACOBI_STREAM : c->variant;   // one sweep: nothing to block
+    fluid::launch_jacobi(c->stream, v1, c->f[x], c->f[x0], c->f[out], c->pitch, c->n, c->own0, c->own1, alpha, beta, b);
     HIP_TRY(hipGetLastError());
     return FLUID_OK;
 }

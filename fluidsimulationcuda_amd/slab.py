@@ -32,10 +32,14 @@ def slab_rows(n, rank, nranks):
 class TorchExchange:
     """The fluid_exchange_fn of include/fluid_amd.h over torch.distributed.
 
-    `fields[id]` is a [n+2, pitch] tensor view of field `id`; rows of it are
+    `fields(id)` returns the [n+2, pitch] tensor view of field `id` as it is
+    placed right now (fields may trade buffers inside a solve); rows of it are
     contiguous, so a halo needs no packing."""
 
     def __init__(self, fields, n, rank, nranks, group=None, stream=None):
+        if not callable(fields):
+            table = fields
+            fields = table.__getitem__
         self.fields, self.n, self.rank, self.nranks, self.group = fields, n, rank, nranks, group
         self.stream = stream        # torch.cuda.Stream the solver's kernels run on (None: CPU tensors)
         self.lo, self.hi = slab_rows(n, rank, nranks)
@@ -43,7 +47,7 @@ class TorchExchange:
         # RCCL moves device memory directly.  gloo cannot, so device rows are
         # staged through host buffers: used only to rehearse the multi-process
         # path on a box with fewer GPUs than ranks (tests, bench --backend gloo).
-        self.staged = fields[0].is_cuda and dist.get_backend(group) != "nccl"
+        self.staged = fields(0).is_cuda and dist.get_backend(group) != "nccl"
 
     def _peer(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
@@ -82,7 +86,7 @@ class TorchExchange:
                 landing.append((rows, buf))
 
         for fid in ids:             # same order on every rank: sends and receives pair up
-            f = self.fields[fid]
+            f = self.fields(fid)
             if self.rank > 0:
                 up = self._peer(self.rank - 1)
                 send(f[lo:lo + depth], up)
@@ -99,7 +103,7 @@ class TorchExchange:
 
     def gather(self, ids):
         for fid in ids:
-            f = self.fields[fid]
+            f = self.fields(fid)
             for r in range(self.nranks):
                 lo, hi = slab_rows(self.n, r, self.nranks)
                 lo -= 1 if r == 0 else 0                    # end slabs own the wall rows
@@ -113,7 +117,7 @@ class TorchExchange:
                     dist.broadcast(f[lo:hi], src=self._peer(r), group=self.group)
 
     def maximum(self, value):
-        dev = "cpu" if self.staged else self.fields[0].device
+        dev = "cpu" if self.staged else self.fields(0).device
         t = torch.tensor([value], dtype=torch.float32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
@@ -124,7 +128,7 @@ class SlabSolver(FluidSolver):
     RCCL can address it; kernels run on torch's current stream so the
     collectives order against them without host synchronisation."""
 
-    def __init__(self, n, rank=None, nranks=None, halo=0, jacobi=capi.JACOBI_STREAM, device=None, group=None):
+    def __init__(self, n, rank=None, nranks=None, halo=0, jacobi=capi.JACOBI_TB, device=None, group=None):
         if rank is None:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         if nranks is None:
@@ -151,17 +155,24 @@ class SlabSolver(FluidSolver):
             super().__init__(n, rank=rank, nranks=nranks, halo=halo, jacobi=jacobi,
                              stream=self.torch_stream.cuda_stream,
                              arena_ptr=self.arena.data_ptr(), arena_bytes=nbytes)
-        self.fields = [self.arena[k * ff.value:(k + 1) * ff.value].view(n + 2, self.pitch)
+        self._ff = ff.value
+        self._views = [self.arena[k * ff.value:(k + 1) * ff.value].view(n + 2, self.pitch)
                        for k in range(capi.NFIELDS)]
         self.exchange = None
         if nranks > 1:
-            self.exchange = TorchExchange(self.fields, n, rank, nranks, group, stream=self.torch_stream)
+            self.exchange = TorchExchange(self.field_tensor, n, rank, nranks, group, stream=self.torch_stream)
             self.set_exchange(self.exchange)
+
+    def field_tensor(self, fid):
+        """[n+2, pitch] view of the buffer field `fid` occupies right now."""
+        slot, rem = divmod(self.field_ptr(fid) - self.arena.data_ptr(), 4 * self._ff)
+        assert rem == 0 and 0 <= slot < capi.NFIELDS
+        return self._views[slot]
 
     def interior(self, field):
         """[n+2, n+2] strided view of a field (ghost ring included)."""
         fid = capi.FIELD_NAMES.index(field) if isinstance(field, str) else int(field)
-        return self.fields[fid][:, self.xoff:self.xoff + self.n + 2]
+        return self.field_tensor(fid)[:, self.xoff:self.xoff + self.n + 2]
 
     def load_global(self, **host_fields):
         """Every rank uploads the rows it computes on (its slab + wall rows);

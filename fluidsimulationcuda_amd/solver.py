@@ -34,7 +34,7 @@ def _host(a, n):
 class FluidSolver:
     """Six resident fields + scratch on one GPU (or one row slab of several)."""
 
-    def __init__(self, n, rank=0, nranks=1, halo=0, jacobi=capi.JACOBI_STREAM, stream=None,
+    def __init__(self, n, rank=0, nranks=1, halo=0, jacobi=capi.JACOBI_TB, stream=None,
                  arena_ptr=None, arena_bytes=0):
         self._h = C.c_void_p()
         self.n = int(n)
@@ -141,6 +141,9 @@ class FluidSolver:
 
     def set_jacobi_variant(self, variant):
         capi.check(capi.lib().fluid_set_jacobi_variant(self._h, variant))
+
+    def set_param(self, key, value):
+        capi.check(capi.lib().fluid_set_param(self._h, key, value))
 
     def timing_enable(self, on=True):
         capi.check(capi.lib().fluid_timing_enable(self._h, 1 if on else 0))

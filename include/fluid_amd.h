@@ -44,8 +44,19 @@ enum {
     FLUID_NFIELDS = 9
 };
 
-/* Jacobi sweep kernels (identical results, different data paths). */
-enum { FLUID_JACOBI_STREAM = 0, FLUID_JACOBI_LDS = 1, FLUID_JACOBI_NAIVE = 2 };
+/* Jacobi kernels (identical results, different data paths).  TB = temporally
+ * blocked: up to 8 sweeps per launch, same bits as 8 single-sweep launches. */
+enum { FLUID_JACOBI_STREAM = 0, FLUID_JACOBI_LDS = 1, FLUID_JACOBI_NAIVE = 2, FLUID_JACOBI_TB = 3 };
+
+/* Tuning knobs for fluid_set_param(); none of them changes results. */
+enum {
+    FLUID_PARAM_TB_MAX_SWEEPS = 0, /* sweeps fused per launch by FLUID_JACOBI_TB: 8 (default), 4 or 2 */
+    FLUID_PARAM_TB_ROWS = 1,       /* output rows per wave strip of FLUID_JACOBI_TB; 0 = auto          */
+    FLUID_PARAM_HALO = 2,          /* multi-GPU ghost-zone depth (clamped to slab height - 1)          */
+    FLUID_PARAM_TB_FAST_DIVISION = 3 /* 1 (default): FLUID_JACOBI_TB may replace x/beta by an exactly equivalent
+                                      reciprocal multiply, after proving the equivalence for that beta on all
+                                      2^32 float inputs on the device; 0: always divide                  */
+};
 
 typedef struct fluid_ctx fluid_ctx;
 
@@ -97,7 +108,9 @@ int fluid_synchronize(fluid_ctx *ctx);
 
 /* Interior rows [*row_lo, *row_hi) owned by this context's slab (1..N+1 for one GPU). */
 int fluid_owned_rows(fluid_ctx *ctx, int *row_lo, int *row_hi);
-/* Device address of row 0 of a field (for the exchange callback). */
+/* Device address of row 0 of a field, valid until the next solver call: a
+ * field keeps its id but may trade buffers with TMP0 inside a solve, so the
+ * exchange callback must ask every time. */
 int fluid_field_ptr(fluid_ctx *ctx, int field, void **dev_ptr);
 
 /* Host <-> device copies of a whole field, or of rows [row_lo,row_hi) of it
@@ -134,6 +147,7 @@ int fluid_residual(fluid_ctx *ctx, int x, int x0, float alpha, float beta, float
 int fluid_absmax_velocity(fluid_ctx *ctx, int u, int v, float *out);
 
 int fluid_set_jacobi_variant(fluid_ctx *ctx, int variant);
+int fluid_set_param(fluid_ctx *ctx, int key, int value);
 
 /* ---- timing: HIP events on the context's stream around every Jacobi solve -- */
 typedef struct fluid_timing {

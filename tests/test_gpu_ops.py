@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 DT, VISC, DIFF = 0.016, 0.0025, 0.1
 SIZES = [1, 2, 3, 4, 5, 14, 30, 61, 64, 126, 255, 256, 257, 1022]
-VARIANTS = [0, 1, 2]          # stream, LDS-tiled, naive-global
+VARIANTS = [0, 1, 2, 3]       # stream, LDS-tiled, naive-global, temporally blocked
 
 
 @pytest.fixture(scope="module")
@@ -200,3 +200,85 @@ def test_reductions(F, oracle):
         assert_bit_equal(s.download("u"), x, "residual must not alter x")
         s.diffuse(0, "u", "v", 1.0, 4.0, 40)
         assert s.residual("u", "v", 1.0, 4.0) < r0
+
+
+# ---- temporally blocked kernel: window / strip / wall edge cases ---------------
+# windows are 64 float4 lanes overlapping by ceil(T/4) per side: 240 owned
+# columns at T=8, 248 at T=4, 248 at T=2 -> sizes straddling those multiples;
+# strips of `rows` output rows overlap by T rows: tiny, ragged and huge strips.
+TB_SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 14, 61, 64, 239, 240, 241, 247, 248, 249, 255, 256, 257, 480, 481, 1022]
+
+
+@pytest.mark.parametrize("max_t", [8, 4, 2])
+@pytest.mark.parametrize("n", TB_SIZES)
+def test_temporal_blocking_matches_oracle(F, oracle, n, max_t):
+    from fluidsimulationcuda_amd import capi
+    rng = np.random.default_rng(500 + n)
+    with F.FluidSolver(n, jacobi=capi.JACOBI_TB) as s:
+        s.set_param(capi.PARAM_TB_MAX_SWEEPS, max_t)
+        for rows in (0, 1, 3, 16, 5000):
+            s.set_param(capi.PARAM_TB_ROWS, rows)
+            for b, (alpha, beta), iters in ((0, (1.0, 4.0), 40), (1, F.coefficients(n, DT, VISC), 22),
+                                            (2, F.coefficients(n, DT, DIFF), 6), (0, (0.7, 3.3), 8)):
+                x, x0 = rnd(rng, n), rnd(rng, n)
+                s.upload(u=x, v=x0)
+                s.diffuse(b, "u", "v", alpha, beta, iters)
+                want = x.copy()
+                oracle.diffuse(b, want, x0, alpha, beta, iters)
+                assert_bit_equal(s.download("u"), want,
+                                 "TB n=%d maxT=%d rows=%d b=%d iters=%d" % (n, max_t, rows, b, iters))
+                assert_bit_equal(s.download("v"), x0, "x0 untouched")
+
+
+def test_temporal_blocking_power_of_two_beta_paths(F, oracle):
+    """beta = 2^k takes the multiply-by-reciprocal path; it must agree with true
+    division on every input class, denormal results included."""
+    from fluidsimulationcuda_amd import capi
+    n = 61
+    rng = np.random.default_rng(77)
+    with F.FluidSolver(n, jacobi=capi.JACOBI_TB) as s:
+        for beta in (4.0, 0.5, 1.0, 1024.0, 2.0 ** -20, 2.0 ** 100):
+            for scale in (1.0, 1e-38, 1e30):
+                x, x0 = rnd(rng, n) * np.float32(scale), rnd(rng, n) * np.float32(scale)
+                s.upload(u=x, v=x0)
+                s.diffuse(0, "u", "v", 1.0, beta, 8)
+                want = x.copy()
+                oracle.diffuse(0, want, x0, 1.0, beta, 8)
+                assert_bit_equal(s.download("u"), want, "beta=%g scale=%g" % (beta, scale))
+
+
+@pytest.mark.parametrize("beta", [3.0, 6.0, 12.0, 10.0, 1.00016, 102.606407, 2682.734, 0.75, 3.3, 5e-5, 7e5])
+def test_temporal_blocking_reciprocal_division_is_exact(F, oracle, beta):
+    """The TB kernel may replace x/beta by (float)((double)x * (1/beta)) once the
+    library has proven the two equal for all 2^32 inputs on the device (or fall
+    back to dividing).  Either way the bits must match the oracle's true
+    division, on ordinary data and on data full of zeros of both signs,
+    denormals and values near overflow."""
+    from fluidsimulationcuda_amd import capi
+    n = 61
+    rng = np.random.default_rng(int(beta * 1000) % 2 ** 31)
+    specials = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-39, -3e-39, 1.17549435e-38, 3e38, -3e38, 1e-30, 6e-45, 9e-45],
+                        dtype=np.float32)
+    with F.FluidSolver(n, jacobi=capi.JACOBI_TB) as s:
+        for fast in (1, 0):
+            s.set_param(capi.PARAM_TB_FAST_DIVISION, fast)
+            for kind in ("uniform", "special", "tiny"):
+                if kind == "uniform":
+                    x, x0 = rnd(rng, n), rnd(rng, n)
+                elif kind == "special":
+                    x = rng.choice(specials, size=(n + 2, n + 2)).astype(np.float32)
+                    x0 = rng.choice(specials, size=(n + 2, n + 2)).astype(np.float32)
+                else:
+                    x = (rnd(rng, n) * np.float32(1e-38)).astype(np.float32)
+                    x0 = (rnd(rng, n) * np.float32(1e-41)).astype(np.float32)
+                for alpha in (1.0, 0.37):
+                    s.upload(u=x, v=x0)
+                    s.diffuse(0, "u", "v", alpha, beta, 8)
+                    want = x.copy()
+                    with np.errstate(all="ignore"):
+                        oracle.diffuse(0, want, x0, alpha, beta, 8)
+                    got = s.download("u")
+                    nan = np.isnan(want)
+                    assert np.array_equal(np.isnan(got), nan)
+                    assert_bit_equal(np.where(nan, 0, got), np.where(nan, 0, want),
+                                     "beta=%g fast=%d %s alpha=%g" % (beta, fast, kind, alpha))

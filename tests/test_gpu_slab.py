@@ -43,12 +43,12 @@ class FakeFabric:
             self.barrier.wait()                      # ... and so are everyone else's
             lo, hi = me.owned_rows
             for fid in ids:
-                mine = me.fields[fid]
+                mine = me.field_tensor(fid)
                 if kind == capi.XCHG_HALO:
                     if rank > 0:                     # pull the rows above my slab from the rank above
-                        mine[lo - depth:lo].copy_(self.solvers[rank - 1].fields[fid][lo - depth:lo])
+                        mine[lo - depth:lo].copy_(self.solvers[rank - 1].field_tensor(fid)[lo - depth:lo])
                     if rank < self.nranks - 1:
-                        mine[hi:hi + depth].copy_(self.solvers[rank + 1].fields[fid][hi:hi + depth])
+                        mine[hi:hi + depth].copy_(self.solvers[rank + 1].field_tensor(fid)[hi:hi + depth])
                 else:                                # gather: pull every other slab (+ wall rows)
                     for r in range(self.nranks):
                         if r == rank:
@@ -56,7 +56,7 @@ class FakeFabric:
                         a, b = slab_rows(me.n, r, self.nranks)
                         a -= 1 if r == 0 else 0
                         b += 1 if r == self.nranks - 1 else 0
-                        mine[a:b].copy_(self.solvers[r].fields[fid][a:b])
+                        mine[a:b].copy_(self.solvers[r].field_tensor(fid)[a:b])
             torch.cuda.synchronize()
             self.barrier.wait()                      # nobody overwrites rows still being read
             return None
@@ -121,7 +121,8 @@ def _init_fake(s, n, rank, nranks, halo, jacobi):
     FluidSolver.__init__(s, n, rank=rank, nranks=nranks, halo=halo, jacobi=jacobi,
                          stream=s.torch_stream.cuda_stream,
                          arena_ptr=s.arena.data_ptr(), arena_bytes=nbytes)
-    s.fields = [s.arena[k * ff.value:(k + 1) * ff.value].view(n + 2, s.pitch) for k in range(capi.NFIELDS)]
+    s._ff = ff.value
+    s._views = [s.arena[k * ff.value:(k + 1) * ff.value].view(n + 2, s.pitch) for k in range(capi.NFIELDS)]
     s.exchange = None
 
 
@@ -138,9 +139,10 @@ def synthetic(n, seed=1):
     return initialize_parameters(n, seed=seed)
 
 
+@pytest.mark.parametrize("jacobi", [0, 3])
 @pytest.mark.parametrize("n,nranks,halo", [(126, 2, 8), (126, 4, 3), (61, 3, 1), (257, 8, 5), (254, 2, 40),
-                                           (126, 2, 7)])
-def test_steps_bit_identical_to_one_gpu(n, nranks, halo):
+                                           (126, 2, 7), (510, 2, 24)])
+def test_steps_bit_identical_to_one_gpu(n, nranks, halo, jacobi):
     """Three full steps: slabs == single context, every field, every bit
     (includes uneven splits, halo depths that do / do not divide 40)."""
     fields = synthetic(n)
@@ -150,9 +152,9 @@ def test_steps_bit_identical_to_one_gpu(n, nranks, halo):
         s.step(2)
 
     want = single(n, fields, body)
-    got, fab = run_ranks(n, nranks, halo, fields, body)
+    got, fab = run_ranks(n, nranks, halo, fields, body, jacobi=jacobi)
     for k in ("u", "v", "dens"):
-        assert_bit_equal(got[k], want[k], "%s, %d slabs halo %d" % (k, nranks, halo))
+        assert_bit_equal(got[k], want[k], "%s, %d slabs halo %d kernel %d" % (k, nranks, halo, jacobi))
     from fluidsimulationcuda_amd import capi
     kinds = [e[0] for e in fab.log[0]]
     assert kinds.count(capi.XCHG_MAX) == 2 * 3            # two advect bounds per step
@@ -198,7 +200,7 @@ def test_advect_small_velocity_uses_bounded_halo():
     assert len(halos) == 1 and halos[0][2] == 5 and not any(e[0] == capi.XCHG_GATHER for e in fab.log[1])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_operators_on_slabs(variant):
     n, nranks = 126, 3
     rng = np.random.default_rng(13)

@@ -19,7 +19,7 @@ def F():
     return F
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("n,iters,steps", [(30, 40, (1, 2, 5)), (61, 40, (1, 2, 5)), (126, 40, (1, 2, 5)),
                                            (126, 20, (1, 2))])
 def test_golden_steps(F, n, iters, steps, variant):
@@ -154,13 +154,45 @@ def test_variants_agree_at_4096(F, oracle):
     rng = np.random.default_rng(3)
     x, x0 = rnd(rng, n), rnd(rng, n)
     outs = []
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         with F.FluidSolver(n, jacobi=variant) as s:
             s.upload(u=x, v=x0)
             s.diffuse(0, "u", "v", 1.0, 4.0, 4)
             outs.append(s.download("u"))
     assert_bit_equal(outs[1], outs[0], "LDS vs stream")
     assert_bit_equal(outs[2], outs[0], "naive vs stream")
+    assert_bit_equal(outs[3], outs[0], "temporally blocked vs stream")
     want = x.copy()
     oracle.diffuse(0, want, x0, 1.0, 4.0, 4)
     assert_bit_equal(outs[0], want, "stream vs oracle, 4 sweeps at 4096^2")
+
+
+def test_temporal_blocking_full_solve_at_4096(F):
+    """40 sweeps, true-division coefficients, 4096^2: 5 fused launches of 8 ==
+    40 single-sweep launches (which test_variants_agree_at_4096 pins to the oracle)."""
+    n = 4094
+    rng = np.random.default_rng(4)
+    x, x0 = rnd(rng, n), rnd(rng, n)
+    a, b = F.coefficients(n, DT, VISC)
+    outs = []
+    for variant in (0, 3):
+        with F.FluidSolver(n, jacobi=variant) as s:
+            s.upload(u=x, v=x0)
+            s.diffuse(1, "u", "v", a, b, 40)
+            outs.append(s.download("u"))
+    assert_bit_equal(outs[1], outs[0], "TB vs stream, 40 sweeps at 4096^2")
+
+
+def test_step_tb_equals_step_stream_at_4096(F):
+    n = 4094
+    from fluidsimulationcuda_amd.harness import initialize_parameters
+    f = initialize_parameters(n)
+    res = []
+    for variant in (0, 3):
+        with F.FluidSolver(n, jacobi=variant) as s:
+            s.upload(**f)
+            s.step(1, use_sources=True)
+            s.step(1)
+            res.append([s.download(k) for k in ("u", "v", "dens")])
+    for a, b, k in zip(res[0], res[1], "uvd"):
+        assert_bit_equal(b, a, "full steps, TB vs stream: " + k)

@@ -22,7 +22,10 @@ import sys
 
 def short(name):
     name = name.replace("void ", "")
-    return name.split("(")[0].replace("fluid::", "")
+    name = name.split("(")[0].replace("fluid::", "")
+    if name.startswith("k_jacobi_tb<"):        # k_jacobi_tb<8, 2> -> k_jacobi_tb<8> (division modes pooled)
+        name = name.split(",")[0] + ">"
+    return name
 
 
 def main():
