@@ -22,6 +22,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this platform needs dmabuf IPC (RCCL / tensor sharing fail otherwise)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 KERNELS = ["stream", "lds", "naive", "tb"]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)

@@ -67,6 +67,7 @@ struct fluid_ctx {
     std::unordered_map<unsigned, int> div_mode;    // beta bits -> proven division mode
     // slab decomposition
     int rank = 0, nranks = 1, own0 = 1, own1 = 1, min_slab = 0, halo = 1;
+    int reach[FLUID_NFIELDS] = {};            // see "row-slab bookkeeping" below
     fluid_exchange_fn xchg = nullptr;
     void* xchg_user = nullptr;
     // timing
@@ -197,21 +198,66 @@ int division_mode(fluid_ctx* c, float beta, float* arg, double* yd)
     return mode;
 }
 
-// ---- operators on the owned slab -----------------------------------------------
-int op_add_source(fluid_ctx* c, int x, int s, float dt)
+// ---- row-slab bookkeeping ------------------------------------------------------
+// reach[f] = how many rows beyond each INNER edge of this slab currently hold the
+// same values as their owner's copy (kEverywhere: the field is known identical
+// on all ranks, e.g. freshly zeroed).  Writers set it (an operator that computes
+// `r` rows past the slab leaves reach r), need() raises it with ONE exchange for
+// all the fields that fall short.  With one slab everything is a no-op.
+constexpr int kEverywhere = 1 << 28;
+
+int exchange_cap(const fluid_ctx* c) { return c->min_slab - 1; }     // rows a neighbour can always supply
+
+void wrote(fluid_ctx* c, int f, int reach) { c->reach[f] = c->nranks > 1 ? reach : kEverywhere; }
+
+int need(fluid_ctx* c, std::initializer_list<int> fields, int reach)
 {
-    fluid::launch_add_source(c->stream, c->f[x], c->f[s], c->pitch, c->lo_all(), c->hi_all(), dt);
+    if (c->nranks == 1 || reach <= 0) return FLUID_OK;
+    if (reach > exchange_cap(c)) return fail(FLUID_E_COMM, "halo of %d rows exceeds the slab height", reach);
+    std::vector<int> ids;
+    for (int f : fields)
+        if (c->reach[f] < reach) ids.push_back(f);
+    if (ids.empty()) return FLUID_OK;
+    if (!c->xchg) return fail(FLUID_E_COMM, "multi-GPU context without an exchange callback");
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    const int rc = c->xchg(c->xchg_user, FLUID_XCHG_HALO, ids.data(), (int)ids.size(), reach, nullptr);
+    if (rc != 0) return fail(FLUID_E_COMM, "halo exchange failed (rc %d)", rc);
+    for (int f : ids) c->reach[f] = reach;
     return FLUID_OK;
 }
 
-// FluidSequential.c:85-104.  Result lands in field x.  With several slabs the
-// ghost zone is `halo` rows deep: one exchange, then `halo` sweeps over a range
-// that shrinks by one row per sweep on each inner edge -- the same arithmetic
-// per cell as the 1-GPU run, so results are bit-identical.  The temporally
-// blocked kernel runs T of those sweeps per launch.  Sweeps ping-pong between
-// x's buffer and TMP0's; if the result ends in TMP0's buffer the two fields
-// trade buffers (pointer swap, no copy) -- field ids, not addresses, are stable.
-int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int iters)
+// interior rows [lo,hi) this slab computes when it works `reach` rows past its inner edges
+void rows(const fluid_ctx* c, int reach, int* lo, int* hi)
+{
+    *lo = std::max(1, c->own0 - reach);
+    *hi = std::min(c->n + 1, c->own1 + reach);
+}
+
+// ---- operators -------------------------------------------------------------------
+int op_add_source(fluid_ctx* c, int x, int s, float dt)
+{
+    // pointwise: valid as far out as both operands are
+    const int reach = c->nranks > 1 ? std::min({c->reach[x], c->reach[s], exchange_cap(c)}) : 0;
+    int lo, hi;
+    rows(c, reach, &lo, &hi);
+    if (lo == 1) lo = 0;                     // wall rows are cells like any other here (FluidSequential.c:78-82)
+    if (hi == c->n + 1) hi = c->n + 2;
+    fluid::launch_add_source(c->stream, c->f[x], c->f[s], c->pitch, lo, hi, dt);
+    wrote(c, x, reach);
+    return FLUID_OK;
+}
+
+// FluidSequential.c:85-104.  Result lands in field x.  A sweep that writes `r`
+// rows past the slab needs x valid r+1 rows out and x0 r rows out, so a solve
+// that starts with reach R runs R sweeps before it must exchange again -- on
+// ranges that shrink one row per sweep per inner edge, the same arithmetic per
+// cell as the 1-GPU run (bit-identical).  `final_reach`: rows past the slab the
+// caller would like valid afterwards (the gradient wants 1).  The temporally
+// blocked kernel runs T of the sweeps per launch.  Sweeps ping-pong between x's
+// buffer and TMP0's; if the result ends in TMP0's buffer the two fields trade
+// buffers (pointer swap, no copy) -- field ids, not addresses, are stable.
+int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int iters, int final_reach = 0)
 {
     if (iters < 0 || (iters & 1)) return fail(FLUID_E_INVALID, "sweep count must be even and >= 0 (got %d)", iters);
     if (x == x0 || x == FLUID_TMP0 || x0 == FLUID_TMP0)
@@ -221,21 +267,24 @@ int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int 
     TRY(timing_begin(c, &stop));
     int cur = x, nxt = FLUID_TMP0;
     const bool multi = c->nranks > 1;
-    const int H = multi ? c->halo : iters;
     float div_arg = beta;
     double yd = 0.0;
     const int divmode = c->variant == fluid::JACOBI_TB ? division_mode(c, beta, &div_arg, &yd) : 0;
-    if (multi) TRY(exchange(c, FLUID_XCHG_HALO, {x, x0}, H));
+    int r = multi ? std::min(c->reach[x], c->reach[x0] + 1) : kEverywhere;    // sweeps possible right now
     for (int k = 0; k < iters;) {
-        const int s = k % H;
-        if (multi && s == 0 && k > 0) TRY(exchange(c, FLUID_XCHG_HALO, {cur}, H));
-        int T = 1;
-        if (c->variant == fluid::JACOBI_TB) {
-            const int room = std::min(H - s, iters - k);
-            T = (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
+        const int remaining = iters - k;
+        if (r < 1) {
+            const int depth = std::max(1, std::min(c->halo, remaining + final_reach));
+            if (c->reach[x0] < depth - 1) TRY(need(c, {cur, x0}, depth));
+            else TRY(need(c, {cur}, depth));
+            r = std::min(c->reach[cur], c->reach[x0] + 1);
         }
-        const int reach = multi ? H - s - T : 0;
-        const int lo = std::max(1, c->own0 - reach), hi = std::min(c->n + 1, c->own1 + reach);
+        const int room = std::min(r, remaining);
+        int T = 1;
+        if (c->variant == fluid::JACOBI_TB)
+            T = (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
+        int lo, hi;
+        rows(c, multi ? std::min(r - T, exchange_cap(c)) : 0, &lo, &hi);
         if (T == 1) {
             const int v = c->variant == fluid::JACOBI_TB ? fluid::JACOBI_STREAM : c->variant;
             fluid::launch_jacobi(c->stream, v, c->f[cur], c->f[x0], c->f[nxt], c->pitch, c->n, lo, hi, alpha, beta, b);
@@ -255,18 +304,24 @@ int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int 
             fluid::launch_jacobi_tb(c->stream, T, divmode, c->f[cur], c->f[x0], c->f[nxt], c->pitch, c->n, lo, hi, rb,
                                     alpha, div_arg, yd, b);
         }
+        r = multi ? std::min(r - T, exchange_cap(c)) : kEverywhere;
+        wrote(c, nxt, r);
         std::swap(cur, nxt);
         k += T;
     }
     HIP_TRY(hipGetLastError());
-    if (cur != x) std::swap(c->f[x], c->f[FLUID_TMP0]);
+    if (cur != x) {
+        std::swap(c->f[x], c->f[FLUID_TMP0]);
+        std::swap(c->reach[x], c->reach[FLUID_TMP0]);
+    }
+    wrote(c, FLUID_TMP0, 0);
     return timing_end(c, stop, iters);
 }
 
 // FluidSequential.c:107-141.  The back-trace reaches dt0*max|vel| cells, so a
 // slab first learns the global bound (wavefront reduction + MAX exchange) and
-// pulls that many rows of the advected field(s) from its neighbours; when the
-// reach exceeds the neighbours' slabs it falls back to gathering whole fields.
+// makes sure that many rows of the advected field(s) are valid past its edges;
+// when the reach exceeds what a neighbour can supply it gathers whole fields.
 int advect_prepare(fluid_ctx* c, std::initializer_list<int> sources, int u, int v, float dt0)
 {
     if (c->nranks == 1) return FLUID_OK;
@@ -276,9 +331,12 @@ int advect_prepare(fluid_ctx* c, std::initializer_list<int> sources, int u, int 
     TRY(reduce_to_host(c, &vmax));
     TRY(exchange(c, FLUID_XCHG_MAX, {}, 0, &vmax));
     const double reach = std::ceil((double)std::fabs(dt0) * (double)vmax) + 2.0;
-    if (!(reach <= (double)(c->min_slab - 1)))     // also catches NaN/inf
-        return exchange(c, FLUID_XCHG_GATHER, sources, 0);
-    return exchange(c, FLUID_XCHG_HALO, sources, (int)reach);
+    if (!(reach <= (double)exchange_cap(c))) {     // also catches NaN/inf
+        TRY(exchange(c, FLUID_XCHG_GATHER, sources, 0));
+        for (int f : sources) c->reach[f] = kEverywhere;
+        return FLUID_OK;
+    }
+    return need(c, sources, (int)reach);
 }
 
 int op_advect(fluid_ctx* c, int b, int d, int d0, int u, int v, float dt)
@@ -286,16 +344,32 @@ int op_advect(fluid_ctx* c, int b, int d, int d0, int u, int v, float dt)
     if (d == d0 || d == u || d == v) return fail(FLUID_E_INVALID, "advect: output must not alias an input");
     const float dt0 = dt * (float)c->n;
     fluid::launch_advect(c->stream, c->f[d], c->f[d0], c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, dt0, b);
+    wrote(c, d, 0);
     return FLUID_OK;
 }
 
-int op_divergence(fluid_ctx* c, int u, int v, int p, int div)
+// FluidSequential.c:143-158.  `want`: rows past the slab on which the caller
+// would like the divergence (so that the pressure solve that follows needs no
+// exchange of its own); u and v are brought in one row further than that.
+int op_divergence(fluid_ctx* c, int u, int v, int p, int div, int want = 0)
 {
     if (p == u || p == v || div == u || div == v || p == div)
         return fail(FLUID_E_INVALID, "divergence: outputs must not alias inputs");
     const float h = 1.0f / (float)c->n;
-    // ghost rows of p are zeroed together with the slab's edge rows by the fused boundary
-    fluid::launch_divergence(c->stream, c->f[u], c->f[v], c->f[p], c->f[div], c->pitch, c->n, c->own0, c->own1, h);
+    int reach = 0;
+    if (c->nranks > 1) {
+        reach = std::max(0, std::min(want, exchange_cap(c) - 1));
+        TRY(need(c, {u, v}, reach + 1));
+        // p = 0 on every row the solve may read: one row further out than the divergence
+        const int z0 = std::max(0, c->own0 - reach - 1), z1 = std::min(c->w, c->own1 + reach + 1);
+        HIP_TRY(hipMemsetAsync(c->f[p] + (size_t)z0 * c->pitch, 0, (size_t)(z1 - z0) * c->pitch * sizeof(float), c->stream));
+    }
+    int lo, hi;
+    rows(c, reach, &lo, &hi);
+    // ghost rows/columns of p and div are written by the fused boundary of the edge rows
+    fluid::launch_divergence(c->stream, c->f[u], c->f[v], c->f[p], c->f[div], c->pitch, c->n, lo, hi, h);
+    wrote(c, div, reach);
+    wrote(c, p, reach + 1);
     return FLUID_OK;
 }
 
@@ -303,7 +377,10 @@ int op_subtract_gradient(fluid_ctx* c, int u, int v, int p)
 {
     if (p == u || p == v || u == v) return fail(FLUID_E_INVALID, "subtract_gradient: fields must be distinct");
     const float h = 1.0f / (float)c->n;
+    TRY(need(c, {p}, 1));
     fluid::launch_subtract_gradient(c->stream, c->f[u], c->f[v], c->f[p], c->pitch, c->n, c->own0, c->own1, h);
+    wrote(c, u, 0);
+    wrote(c, v, 0);
     return FLUID_OK;
 }
 
@@ -318,14 +395,13 @@ void coefficients(int n, float dt, float coef, float* alpha, float* beta)
     *beta = 1.0f + four_a;
 }
 
-// divergence -> 40-sweep pressure solve -> gradient subtraction
-// (FluidSequential.c:213-223 and :238-240)
+// divergence -> pressure solve -> gradient subtraction (FluidSequential.c:213-223
+// and :238-240).  On slabs: ONE exchange (u, v, iters+2 rows) covers the divergence,
+// every sweep of the solve and the gradient's one-row halo of p.
 int project(fluid_ctx* c, int u, int v, int p, int div, int iters)
 {
-    TRY(exchange(c, FLUID_XCHG_HALO, {u, v}, 1));
-    TRY(op_divergence(c, u, v, p, div));
-    TRY(op_diffuse(c, 0, p, div, 1.0f, 4.0f, iters));
-    TRY(exchange(c, FLUID_XCHG_HALO, {p}, 1));
+    TRY(op_divergence(c, u, v, p, div, std::min(iters, c->halo - 1)));
+    TRY(op_diffuse(c, 0, p, div, 1.0f, 4.0f, iters, /*final_reach=*/1));
     return op_subtract_gradient(c, u, v, p);
 }
 
@@ -338,6 +414,9 @@ int vel_step(fluid_ctx* c, float dt, float visc, int iters)
     TRY(op_add_source(c, U, U0, dt));
     TRY(op_add_source(c, V, V0, dt));
     coefficients(c->n, dt, visc, &alpha, &beta);
+    // one exchange feeds both solves: right-hand sides iters-1 rows out, first guesses iters rows
+    const int h = std::min(iters, c->halo);
+    TRY(need(c, {U, V, U0, V0}, h));
     TRY(op_diffuse(c, 1, U0, U, alpha, beta, iters));
     TRY(op_diffuse(c, 2, V0, V, alpha, beta, iters));
     TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
@@ -360,10 +439,42 @@ int dens_step(fluid_ctx* c, float dt, float diff, int iters)
     return op_advect(c, 0, X, X0, FLUID_U, FLUID_V, dt);
 }
 
+// One loop body of the reference's main.  The density's source term and its
+// halo are brought forward so that ONE exchange serves all three diffusions
+// (they are independent of each other; the arithmetic per cell is unchanged).
+int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
+{
+    if (c->nranks > 1 && iters > 0) {
+        TRY(op_add_source(c, FLUID_U, FLUID_U_PREV, dt));
+        TRY(op_add_source(c, FLUID_V, FLUID_V_PREV, dt));
+        TRY(op_add_source(c, FLUID_DENS, FLUID_DENS_PREV, dt));
+        // right-hand sides and first guesses together (zeroed sources are valid everywhere and skipped)
+        const int h = std::min(iters, c->halo);
+        TRY(need(c, {FLUID_U, FLUID_V, FLUID_DENS, FLUID_U_PREV, FLUID_V_PREV, FLUID_DENS_PREV}, h));
+        float alpha, beta;
+        coefficients(c->n, dt, visc, &alpha, &beta);
+        TRY(op_diffuse(c, 1, FLUID_U_PREV, FLUID_U, alpha, beta, iters));
+        TRY(op_diffuse(c, 2, FLUID_V_PREV, FLUID_V, alpha, beta, iters));
+        TRY(project(c, FLUID_U_PREV, FLUID_V_PREV, FLUID_U, FLUID_V, iters));
+        TRY(advect_prepare(c, {FLUID_U_PREV, FLUID_V_PREV}, FLUID_U_PREV, FLUID_V_PREV, dt * (float)c->n));
+        TRY(op_advect(c, 1, FLUID_U, FLUID_U_PREV, FLUID_U_PREV, FLUID_V_PREV, dt));
+        TRY(op_advect(c, 2, FLUID_V, FLUID_V_PREV, FLUID_U_PREV, FLUID_V_PREV, dt));
+        TRY(project(c, FLUID_U, FLUID_V, FLUID_U_PREV, FLUID_V_PREV, iters));
+        coefficients(c->n, dt, diff, &alpha, &beta);
+        TRY(op_diffuse(c, 0, FLUID_DENS_PREV, FLUID_DENS, alpha, beta, iters));
+        TRY(advect_prepare(c, {FLUID_DENS_PREV}, FLUID_U, FLUID_V, dt * (float)c->n));
+        return op_advect(c, 0, FLUID_DENS, FLUID_DENS_PREV, FLUID_U, FLUID_V, dt);
+    }
+    TRY(vel_step(c, dt, visc, iters));
+    return dens_step(c, dt, diff, iters);
+}
+
 int zero_sources(fluid_ctx* c)
 {
-    for (int id : {FLUID_U_PREV, FLUID_V_PREV, FLUID_DENS_PREV})
+    for (int id : {FLUID_U_PREV, FLUID_V_PREV, FLUID_DENS_PREV}) {
         HIP_TRY(hipMemsetAsync(c->f[id], 0, c->field_floats * sizeof(float), c->stream));
+        wrote(c, id, kEverywhere);
+    }
     return FLUID_OK;
 }
 
@@ -374,8 +485,10 @@ int copy_rows(fluid_ctx* c, int field, float* host, const float* chost, int row_
     float* dev = c->f[field] + (size_t)row_lo * c->pitch + XOFF;
     const size_t hp = (size_t)c->w * sizeof(float), dp = (size_t)c->pitch * sizeof(float);
     const size_t rows = (size_t)(row_hi - row_lo);
-    if (to_device)
+    if (to_device) {
+        c->reach[field] = 0;     // the caller vouches only for its own rows
         HIP_TRY(hipMemcpy2DAsync(dev, dp, chost + (size_t)row_lo * c->w, hp, hp, rows, hipMemcpyHostToDevice, c->stream));
+    }
     else
         HIP_TRY(hipMemcpy2DAsync(host + (size_t)row_lo * c->w, hp, dev, dp, hp, rows, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -442,9 +555,10 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
     c->own1 = c->own0 + base + (cfg->rank < rem ? 1 : 0);
     c->min_slab = base;
     // ghost-zone depth: never reaches a neighbour's wall rows (depth <= slab-1)
-    // default: ~6 % redundant rows buys 40 sweeps per exchange on tall slabs (halo rows are
-    // latency-bound on xGMI: 32 KiB per row at 8192^2), fewer on short ones
-    const int want = cfg->halo > 0 ? cfg->halo : std::max(4, std::min(40, base / 16));
+    // default: deep enough that a 40-sweep solve (+ the gradient's row) needs one exchange -- halo
+    // rows are latency-bound on xGMI (32 KiB per row at 8192^2) -- at ~4 % redundant rows on a
+    // 1024-row slab; shallower on short slabs
+    const int want = cfg->halo > 0 ? cfg->halo : std::max(4, std::min(42, base / 8));
     c->halo = P > 1 ? std::max(1, std::min(want, base - 1)) : 1;
     const size_t bytes = c->field_floats * FLUID_NFIELDS * sizeof(float);
     int rc = FLUID_OK;
@@ -570,10 +684,13 @@ int fluid_fill(fluid_ctx* c, int field, float value)
     TRY(check_fields(c, {field}));
     if (value == 0.0f && !std::signbit(value)) {
         HIP_TRY(hipMemsetAsync(c->f[field], 0, c->field_floats * sizeof(float), c->stream));
+        wrote(c, field, kEverywhere);
         return FLUID_OK;
     }
     std::vector<float> row((size_t)c->w * c->w, value);
-    return fluid_upload(c, field, row.data());
+    TRY(fluid_upload(c, field, row.data()));
+    wrote(c, field, kEverywhere);
+    return FLUID_OK;
 }
 
 int fluid_set_jacobi_variant(fluid_ctx* c, int variant)
@@ -641,8 +758,7 @@ int fluid_step(fluid_ctx* c, float dt, float diff, float visc, int iters, int ns
     if (nsteps < 0) return fail(FLUID_E_INVALID, "nsteps < 0");
     for (int z = 0; z < nsteps; ++z) {
         if (!(use_sources && z == 0)) TRY(zero_sources(c));
-        TRY(vel_step(c, dt, visc, iters));
-        TRY(dens_step(c, dt, diff, iters));
+        TRY(full_step(c, dt, diff, visc, iters));
     }
     HIP_TRY(hipGetLastError());
     return FLUID_OK;
@@ -676,9 +792,10 @@ int fluid_op_jacobi_sweep(fluid_ctx* c, int b, int x, int x0, int out, float alp
     TRY(check_fields(c, {x, x0, out}));
     if (b < 0 || b > 2) return fail(FLUID_E_INVALID, "b must be 0, 1 or 2");
     if (out == x || out == x0) return fail(FLUID_E_INVALID, "jacobi_sweep: out must not alias an input");
-    TRY(exchange(c, FLUID_XCHG_HALO, {x}, 1));
+    TRY(need(c, {x}, 1));
     const int v1 = c->variant == fluid::JACOBI_TB ? fluid::JACOBI_STREAM : c->variant;   // one sweep: nothing to block
     fluid::launch_jacobi(c->stream, v1, c->f[x], c->f[x0], c->f[out], c->pitch, c->n, c->own0, c->own1, alpha, beta, b);
+    wrote(c, out, 0);
     HIP_TRY(hipGetLastError());
     return FLUID_OK;
 }
@@ -707,7 +824,6 @@ int fluid_op_divergence(fluid_ctx* c, int u, int v, int p, int div)
 {
     TRY(check_ctx(c));
     TRY(check_fields(c, {u, v, p, div}));
-    TRY(exchange(c, FLUID_XCHG_HALO, {u, v}, 1));
     TRY(op_divergence(c, u, v, p, div));
     HIP_TRY(hipGetLastError());
     return FLUID_OK;
@@ -717,7 +833,6 @@ int fluid_op_subtract_gradient(fluid_ctx* c, int u, int v, int p)
 {
     TRY(check_ctx(c));
     TRY(check_fields(c, {u, v, p}));
-    TRY(exchange(c, FLUID_XCHG_HALO, {p}, 1));
     TRY(op_subtract_gradient(c, u, v, p));
     HIP_TRY(hipGetLastError());
     return FLUID_OK;
@@ -729,7 +844,7 @@ int fluid_residual(fluid_ctx* c, int x, int x0, float alpha, float beta, float* 
     TRY(check_ctx(c));
     TRY(check_fields(c, {x, x0}));
     if (!out) return fail(FLUID_E_INVALID, "null pointer");
-    TRY(exchange(c, FLUID_XCHG_HALO, {x}, 1));
+    TRY(need(c, {x}, 1));
     HIP_TRY(hipMemsetAsync(c->d_scalar, 0, sizeof(unsigned), c->stream));
     fluid::launch_residual(c->stream, c->f[x], c->f[x0], c->pitch, c->n, c->own0, c->own1, alpha, beta, c->d_scalar);
     TRY(reduce_to_host(c, out));

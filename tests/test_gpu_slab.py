@@ -141,7 +141,7 @@ def synthetic(n, seed=1):
 
 @pytest.mark.parametrize("jacobi", [0, 3])
 @pytest.mark.parametrize("n,nranks,halo", [(126, 2, 8), (126, 4, 3), (61, 3, 1), (257, 8, 5), (254, 2, 40),
-                                           (126, 2, 7), (510, 2, 24)])
+                                           (126, 2, 7), (510, 2, 24), (1022, 2, 42), (1022, 4, 0)])
 def test_steps_bit_identical_to_one_gpu(n, nranks, halo, jacobi):
     """Three full steps: slabs == single context, every field, every bit
     (includes uneven splits, halo depths that do / do not divide 40)."""
@@ -162,6 +162,10 @@ def test_steps_bit_identical_to_one_gpu(n, nranks, halo, jacobi):
     depth = max(1, min(halo, n // nranks - 1))
     per_solve = 1 + (40 - 1) // depth
     assert kinds.count(capi.XCHG_HALO) <= 3 * (5 * per_solve + 2 * 2 + 2 + 1)
+    if depth >= 42:
+        # tall slabs, deep ghost zones: diffusion x3 share one exchange, each projection
+        # needs one, each advect at most one (SURVEY.md 8(e) asks for one PER SWEEP: 200)
+        assert kinds.count(capi.XCHG_HALO) <= 3 * 5
 
 
 def test_advect_large_velocity_falls_back_to_gather():
