@@ -122,10 +122,20 @@ def cpu_baseline(n, fields, iters):
     else:
         eng.diffuse(0, p, div, 1.0, 4.0, iters)
     t_solve = time.perf_counter() - t0
-    return {"value": w * w / (t_solve / iters) / 1e6, "unit": "Mcells/s per Jacobi iter", "cores": 1,
-            "kind": "reference" if use_ref else "port", "ms_per_step": t_step * 1e3,
-            "sample": "1 full step (200 sweeps) + one %d-sweep pressure solve at %dx%d, gcc -O2, 1 thread"
-                      % (iters, w, w)}
+    out = {"value": w * w / (t_solve / iters) / 1e6, "unit": "Mcells/s per Jacobi iter", "cores": 1,
+           "kind": "reference" if use_ref else "port", "ms_per_step": t_step * 1e3,
+           "sample": "1 full step (200 sweeps) + one %d-sweep pressure solve at %dx%d, gcc -O2, 1 thread"
+                     % (iters, w, w)}
+    # secondary line: the restatement's sweep split into row bands over all host cores
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if cores > 1:
+        p2 = np.zeros((w, w), np.float32)
+        t0 = time.perf_counter()
+        Oracle().diffuse_threaded(0, p2, div, 1.0, 4.0, 8, cores)
+        t_mt = (time.perf_counter() - t0) / 8
+        out["all_cores"] = {"value": w * w / t_mt / 1e6, "unit": "Mcells/s per Jacobi iter", "cores": cores,
+                            "kind": "port", "sample": "8 sweeps of the pressure solve, row bands over %d threads" % cores}
+    return out
 
 
 def main():

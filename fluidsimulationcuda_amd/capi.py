@@ -31,8 +31,13 @@ class Config(C.Structure):
                 ("arena_bytes", C.c_size_t)]
 
 
+TIME_SOURCE, TIME_DIFFUSION, TIME_DIVERGENCE, TIME_PROJECTION, TIME_ADVECTION = range(5)
+TIMING_CATEGORIES = ("source", "diffusion", "divergence", "projection", "advection")
+
+
 class Timing(C.Structure):
-    _fields_ = [("jacobi_ms", C.c_double), ("sweeps", C.c_longlong), ("solves", C.c_longlong)]
+    _fields_ = [("jacobi_ms", C.c_double), ("sweeps", C.c_longlong), ("solves", C.c_longlong),
+                ("category_ms", C.c_double * 5), ("category_calls", C.c_longlong * 5)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int,
@@ -77,6 +82,7 @@ SIGNATURES = {
     "fluid_set_param": [_ctx, _i, _i],
     "fluid_timing_enable": [_ctx, _i],
     "fluid_timing_read": [_ctx, C.POINTER(Timing), _i],
+    "fluid_op_diffuse_tol": [_ctx, _i, _i, _i, _f, _f, _f, _i, _i, C.POINTER(_i), C.POINTER(_f)],
     "fluid_set_exchange": [_ctx, EXCHANGE_FN, C.c_void_p],
 }
 # symbols with a non-status return type

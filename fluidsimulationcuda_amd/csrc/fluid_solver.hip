@@ -72,10 +72,12 @@ struct fluid_ctx {
     void* xchg_user = nullptr;
     // timing
     bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    struct Ev { hipEvent_t a, b; int cat; };
+    std::vector<Ev> ev_pool;
     size_t ev_used = 0;
-    double jacobi_ms = 0.0;
-    long long sweeps = 0, solves = 0, pending_sweeps = 0;
+    double cat_ms[FLUID_TIMING_CATEGORIES] = {};
+    long long cat_calls[FLUID_TIMING_CATEGORIES] = {};
+    long long sweeps = 0, pending_sweeps = 0;
 
     bool valid_field(int id) const { return id >= 0 && id < FLUID_NFIELDS; }
     int lo_all() const { return own0 - (rank == 0 ? 1 : 0); }          // owned rows incl. ghost row
@@ -123,19 +125,20 @@ int reduce_to_host(fluid_ctx* c, float* out)
 }
 
 // ---- timing ---------------------------------------------------------------
-int timing_begin(fluid_ctx* c, hipEvent_t* stop_out)
+int timing_begin(fluid_ctx* c, int cat, hipEvent_t* stop_out)
 {
     *stop_out = nullptr;
     if (!c->timing) return FLUID_OK;
     if (c->ev_used == c->ev_pool.size()) {
-        hipEvent_t a, b;
-        HIP_TRY(hipEventCreate(&a));
-        HIP_TRY(hipEventCreate(&b));
-        c->ev_pool.emplace_back(a, b);
+        fluid_ctx::Ev e{};
+        HIP_TRY(hipEventCreate(&e.a));
+        HIP_TRY(hipEventCreate(&e.b));
+        c->ev_pool.push_back(e);
     }
     auto& p = c->ev_pool[c->ev_used++];
-    HIP_TRY(hipEventRecord(p.first, c->stream));
-    *stop_out = p.second;
+    p.cat = cat;
+    HIP_TRY(hipEventRecord(p.a, c->stream));
+    *stop_out = p.b;
     return FLUID_OK;
 }
 
@@ -153,15 +156,24 @@ int timing_collect(fluid_ctx* c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (size_t k = 0; k < c->ev_used; ++k) {
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k].first, c->ev_pool[k].second));
-        c->jacobi_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k].a, c->ev_pool[k].b));
+        c->cat_ms[c->ev_pool[k].cat] += ms;
+        c->cat_calls[c->ev_pool[k].cat] += 1;
     }
-    c->solves += (long long)c->ev_used;
     c->sweeps += c->pending_sweeps;
     c->pending_sweeps = 0;
     c->ev_used = 0;
     return FLUID_OK;
 }
+
+// RAII-free helper: time one operator launch under category `cat`
+#define TIMED(c, cat, stmt)                      \
+    do {                                         \
+        hipEvent_t stop_;                        \
+        TRY(timing_begin((c), (cat), &stop_));   \
+        stmt;                                    \
+        TRY(timing_end((c), stop_, 0));          \
+    } while (0)
 
 // Division mode for `beta` in the temporally blocked kernel: 0 = true division,
 // 1 = multiply by the exact reciprocal (beta a power of two), 2 = f64 reciprocal
@@ -243,7 +255,7 @@ int op_add_source(fluid_ctx* c, int x, int s, float dt)
     rows(c, reach, &lo, &hi);
     if (lo == 1) lo = 0;                     // wall rows are cells like any other here (FluidSequential.c:78-82)
     if (hi == c->n + 1) hi = c->n + 2;
-    fluid::launch_add_source(c->stream, c->f[x], c->f[s], c->pitch, lo, hi, dt);
+    TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->f[x], c->f[s], c->pitch, lo, hi, dt));
     wrote(c, x, reach);
     return FLUID_OK;
 }
@@ -264,7 +276,7 @@ int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int 
         return fail(FLUID_E_INVALID, "diffuse: x, x0 and TMP0 must be distinct fields");
     if (iters == 0) return FLUID_OK;
     hipEvent_t stop;
-    TRY(timing_begin(c, &stop));
+    TRY(timing_begin(c, FLUID_TIME_DIFFUSION, &stop));
     int cur = x, nxt = FLUID_TMP0;
     const bool multi = c->nranks > 1;
     float div_arg = beta;
@@ -343,7 +355,8 @@ int op_advect(fluid_ctx* c, int b, int d, int d0, int u, int v, float dt)
 {
     if (d == d0 || d == u || d == v) return fail(FLUID_E_INVALID, "advect: output must not alias an input");
     const float dt0 = dt * (float)c->n;
-    fluid::launch_advect(c->stream, c->f[d], c->f[d0], c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, dt0, b);
+    TIMED(c, FLUID_TIME_ADVECTION,
+          fluid::launch_advect(c->stream, c->f[d], c->f[d0], c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, dt0, b));
     wrote(c, d, 0);
     return FLUID_OK;
 }
@@ -367,7 +380,8 @@ int op_divergence(fluid_ctx* c, int u, int v, int p, int div, int want = 0)
     int lo, hi;
     rows(c, reach, &lo, &hi);
     // ghost rows/columns of p and div are written by the fused boundary of the edge rows
-    fluid::launch_divergence(c->stream, c->f[u], c->f[v], c->f[p], c->f[div], c->pitch, c->n, lo, hi, h);
+    TIMED(c, FLUID_TIME_DIVERGENCE,
+          fluid::launch_divergence(c->stream, c->f[u], c->f[v], c->f[p], c->f[div], c->pitch, c->n, lo, hi, h));
     wrote(c, div, reach);
     wrote(c, p, reach + 1);
     return FLUID_OK;
@@ -378,7 +392,8 @@ int op_subtract_gradient(fluid_ctx* c, int u, int v, int p)
     if (p == u || p == v || u == v) return fail(FLUID_E_INVALID, "subtract_gradient: fields must be distinct");
     const float h = 1.0f / (float)c->n;
     TRY(need(c, {p}, 1));
-    fluid::launch_subtract_gradient(c->stream, c->f[u], c->f[v], c->f[p], c->pitch, c->n, c->own0, c->own1, h);
+    TIMED(c, FLUID_TIME_PROJECTION,
+          fluid::launch_subtract_gradient(c->stream, c->f[u], c->f[v], c->f[p], c->pitch, c->n, c->own0, c->own1, h));
     wrote(c, u, 0);
     wrote(c, v, 0);
     return FLUID_OK;
@@ -614,8 +629,8 @@ int fluid_destroy(fluid_ctx* c)
     if (!c) return FLUID_OK;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->ev_pool) {
-        (void)hipEventDestroy(p.first);
-        (void)hipEventDestroy(p.second);
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
     }
     if (c->d_scalar) (void)hipFree(c->d_scalar);
     if (c->h_scalar) (void)hipHostFree(c->h_scalar);
@@ -876,13 +891,46 @@ int fluid_timing_read(fluid_ctx* c, fluid_timing* out, int reset)
     TRY(check_ctx(c));
     if (!out) return fail(FLUID_E_INVALID, "null pointer");
     TRY(timing_collect(c));
-    out->jacobi_ms = c->jacobi_ms;
+    out->jacobi_ms = c->cat_ms[FLUID_TIME_DIFFUSION];
     out->sweeps = c->sweeps;
-    out->solves = c->solves;
-    if (reset) {
-        c->jacobi_ms = 0.0;
-        c->sweeps = c->solves = 0;
+    out->solves = c->cat_calls[FLUID_TIME_DIFFUSION];
+    for (int k = 0; k < FLUID_TIMING_CATEGORIES; ++k) {
+        out->category_ms[k] = c->cat_ms[k];
+        out->category_calls[k] = c->cat_calls[k];
     }
+    if (reset) {
+        for (int k = 0; k < FLUID_TIMING_CATEGORIES; ++k) {
+            c->cat_ms[k] = 0.0;
+            c->cat_calls[k] = 0;
+        }
+        c->sweeps = 0;
+    }
+    return FLUID_OK;
+}
+
+// Opt-in, NOT the reference's behaviour (it always runs a fixed count,
+// FluidSequential.c:91): Jacobi in blocks of `check_every` sweeps until the
+// max-norm residual drops to `tol` or `max_iters` is reached.
+int fluid_op_diffuse_tol(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, float tol, int max_iters,
+                         int check_every, int* iters_done, float* residual)
+{
+    TRY(check_ctx(c));
+    TRY(check_fields(c, {x, x0}));
+    if (b < 0 || b > 2) return fail(FLUID_E_INVALID, "b must be 0, 1 or 2");
+    if (check_every < 2 || (check_every & 1) || max_iters < 0 || !(tol >= 0.f))
+        return fail(FLUID_E_INVALID, "diffuse_tol: check_every must be even and >= 2, max_iters >= 0, tol >= 0");
+    int done = 0;
+    float res = 0.f;
+    TRY(fluid_residual(c, x, x0, alpha, beta, &res));
+    while (res > tol && done < max_iters) {
+        const int blk = std::min(check_every, (max_iters - done) & ~1);
+        if (blk <= 0) break;
+        TRY(op_diffuse(c, b, x, x0, alpha, beta, blk));
+        done += blk;
+        TRY(fluid_residual(c, x, x0, alpha, beta, &res));
+    }
+    if (iters_done) *iters_done = done;
+    if (residual) *residual = res;
     return FLUID_OK;
 }
 

@@ -30,8 +30,11 @@ def initialize_parameters(n, seed=1):
 
 
 def run_steps(solver, steps, dt=DT, diff=DIFF, visc=VIS, iters=ITERS, first_uses_sources=True):
-    """Z steps as the reference's main does, returning what it prints
-    (FluidSequential.c:323-324): mean seconds per step and per Jacobi sweep."""
+    """Z steps as the reference's main does (FluidSequential.c:289-312), returning
+    the means it prints (:323-324), in seconds: Tot per step; Source, Divergence,
+    Advection, Projection per call; Diffusion per Jacobi SWEEP (the reference
+    divides its diffusion time by 40).  Unlike the reference, which times only
+    the first call of each kind per step, every call is timed (HIP events)."""
     solver.synchronize()
     solver.timing_enable(True)
     solver.timing_read(reset=True)
@@ -42,4 +45,82 @@ def run_steps(solver, steps, dt=DT, diff=DIFF, visc=VIS, iters=ITERS, first_uses
     wall = time.perf_counter() - t0
     t = solver.timing_read(reset=True)
     solver.timing_enable(False)
-    return {"Tot": wall / steps, "Diffusion": t["jacobi_ms"] * 1e-3 / max(t["sweeps"], 1), "sweeps": t["sweeps"]}
+
+    def per_call(name):
+        return t[name + "_ms"] * 1e-3 / max(t[name + "_calls"], 1)
+
+    return {"Tot": wall / steps, "Source": per_call("source"),
+            "Diffusion": t["jacobi_ms"] * 1e-3 / max(t["sweeps"], 1), "Divergence": per_call("divergence"),
+            "Advection": per_call("advection"), "Projection": per_call("projection"), "sweeps": t["sweeps"]}
+
+
+def format_report(r):
+    """The reference's closing printf (FluidSequential.c:323-324), same labels and order."""
+    return "Tot %f\nSource %f\nDiffusion %f\nDivergence %f\nAdvection %f\nProjection %f\n" % (
+        r["Tot"], r["Source"], r["Diffusion"], r["Divergence"], r["Advection"], r["Projection"])
+
+
+# ---- state dump / load (SURVEY.md 8(f) rank 3; the reference keeps state only in memory) ----
+STATE_FIELDS = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev")
+_MAGIC = b"FLUIDF32"
+
+
+def save_state(solver, path, step_index=0):
+    """Raw little-endian dump: magic, int32 N, int32 step index, then the six
+    (N+2)^2 float32 fields in the order of the reference's main (:277-282)."""
+    with open(path, "wb") as f:
+        f.write(_MAGIC)
+        np.array([solver.n, step_index], dtype="<i4").tofile(f)
+        for name in STATE_FIELDS:
+            solver.download(name).astype("<f4").tofile(f)
+
+
+def load_state(solver, path):
+    """Inverse of save_state; returns the stored step index."""
+    with open(path, "rb") as f:
+        if f.read(8) != _MAGIC:
+            raise ValueError("%s is not a fluid state file" % path)
+        n, step_index = np.fromfile(f, dtype="<i4", count=2)
+        if n != solver.n:
+            raise ValueError("state is for N=%d, solver has N=%d" % (n, solver.n))
+        w = n + 2
+        for name in STATE_FIELDS:
+            a = np.fromfile(f, dtype="<f4", count=w * w)
+            if a.size != w * w:
+                raise ValueError("truncated state file")
+            solver.upload(**{name: a.reshape(w, w)})
+    return int(step_index)
+
+
+def print_state_grid(dens, u, v, out=None):
+    """Text dump in the layout of the reference's printStateGrid (FluidSequential.c:32-52)."""
+    import sys
+    out = out or sys.stdout
+    out.write("---------------------------------------\nDENSITY\n")
+    for row in dens:
+        out.write("".join("[%f] " % x for x in row) + "\n")
+    out.write("\n\nVELOCITY\n")
+    for ru, rv in zip(u, v):
+        out.write("".join("[%f, %f] " % (a, b) for a, b in zip(ru, rv)) + "\n")
+
+
+def main(argv=None):
+    """python -m fluidsimulationcuda_amd.harness [--grid W] [--steps Z]: the reference's
+    main() on the MI355X -- synthetic input, Z steps, its closing report."""
+    import argparse
+    from .solver import FluidSolver
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=50)        # Z, FluidSequential.c:10
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args(argv)
+    n = a.grid - 2
+    with FluidSolver(n) as s:
+        s.upload(**initialize_parameters(n, a.seed))
+        s.step(1, use_sources=True)                          # warm-up incl. one-time division proofs
+        s.upload(**initialize_parameters(n, a.seed))
+        print(format_report(run_steps(s, a.steps)), end="")
+
+
+if __name__ == "__main__":
+    main()

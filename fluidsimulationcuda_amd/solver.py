@@ -151,7 +151,19 @@ class FluidSolver:
     def timing_read(self, reset=True):
         t = capi.Timing()
         capi.check(capi.lib().fluid_timing_read(self._h, C.byref(t), 1 if reset else 0))
-        return {"jacobi_ms": t.jacobi_ms, "sweeps": t.sweeps, "solves": t.solves}
+        out = {"jacobi_ms": t.jacobi_ms, "sweeps": t.sweeps, "solves": t.solves}
+        for k, name in enumerate(capi.TIMING_CATEGORIES):
+            out[name + "_ms"] = t.category_ms[k]
+            out[name + "_calls"] = t.category_calls[k]
+        return out
+
+    def diffuse_tol(self, b, x, x0, alpha, beta, tol, max_iters=10000, check_every=8):
+        """Opt-in, not the reference's behaviour: sweep until the residual <= tol.
+        Returns (sweeps done, final residual)."""
+        it, res = C.c_int(), C.c_float()
+        capi.check(capi.lib().fluid_op_diffuse_tol(self._h, b, _fid(x), _fid(x0), alpha, beta, tol, max_iters,
+                                                   check_every, C.byref(it), C.byref(res)))
+        return it.value, res.value
 
     def set_exchange(self, fn):
         """fn(kind, fields, depth, scalar_or_None) -> new scalar or None; raises on failure."""

@@ -149,14 +149,30 @@ int fluid_absmax_velocity(fluid_ctx *ctx, int u, int v, float *out);
 int fluid_set_jacobi_variant(fluid_ctx *ctx, int variant);
 int fluid_set_param(fluid_ctx *ctx, int key, int value);
 
-/* ---- timing: HIP events on the context's stream around every Jacobi solve -- */
+/* ---- timing: HIP events on the context's stream around every operator -------
+ * Categories are the reference's per-kernel timers (timeSource, timeDiffusion,
+ * timeDivergence, timeProjection, timeAdvection: FluidSequential.c:16,192-234). */
+enum {
+    FLUID_TIME_SOURCE = 0, FLUID_TIME_DIFFUSION = 1, FLUID_TIME_DIVERGENCE = 2,
+    FLUID_TIME_PROJECTION = 3, FLUID_TIME_ADVECTION = 4, FLUID_TIMING_CATEGORIES = 5
+};
 typedef struct fluid_timing {
-    double jacobi_ms;      /* device time inside Jacobi solves since the last reset */
+    double jacobi_ms;      /* device time inside Jacobi solves since the last reset (= category DIFFUSION) */
     long long sweeps;      /* Jacobi sweeps executed in those solves                */
     long long solves;
+    double category_ms[FLUID_TIMING_CATEGORIES];
+    long long category_calls[FLUID_TIMING_CATEGORIES];
 } fluid_timing;
 int fluid_timing_enable(fluid_ctx *ctx, int on);
 int fluid_timing_read(fluid_ctx *ctx, fluid_timing *out, int reset);
+
+/* ---- opt-in extension (changes results: NOT the reference's fixed 40 sweeps) -
+ * Jacobi in blocks of `check_every` (even) sweeps until the max-norm residual
+ * max|beta*x - alpha*(L+R+U+D) - x0| <= tol, or max_iters.  The report proposes
+ * a convergence-aware solve as future work (document/main.tex:356). */
+int fluid_op_diffuse_tol(fluid_ctx *ctx, int b, int x, int x0, float alpha, float beta,
+                         float tol, int max_iters, int check_every,
+                         int *iters_done, float *residual);
 
 /* ---- multi-GPU: row slabs, one context (and one process) per GPU ----------
  * The solver calls back whenever rows must move between slabs; the host layer

@@ -81,6 +81,29 @@ void fo_jacobi_sweep(int n, int b, const float *x, const float *x0, float *out,
     fo_set_bnd(n, b, out);
 }
 
+/* Rows [row_lo,row_hi) of one sweep, no boundary: lets bench.py's all-cores
+ * baseline split a sweep over host threads (set_bnd follows once all bands are
+ * done).  Same arithmetic as fo_jacobi_sweep. */
+void fo_jacobi_rows(int n, const float *x, const float *x0, float *out,
+                    float alpha, float beta, int row_lo, int row_hi)
+{
+    const size_t w = (size_t)n + 2;
+    for (int i = row_lo; i < row_hi; ++i) {
+        const float *up = x + (size_t)(i - 1) * w;
+        const float *me = x + (size_t)i * w;
+        const float *dn = x + (size_t)(i + 1) * w;
+        const float *rhs = x0 + (size_t)i * w;
+        float *o = out + (size_t)i * w;
+        for (int j = 1; j <= n; ++j) {
+            float nb = me[j - 1] + me[j + 1];
+            nb = nb + up[j];
+            nb = nb + dn[j];
+            const float num = rhs[j] + alpha * nb;
+            o[j] = num / beta;
+        }
+    }
+}
+
 /* Whole solve (FluidSequential.c:85-104).  The initial guess is whatever x
  * holds on entry, ghosts included.  The reference ping-pongs pointers and is
  * only safe for an even count (:100,103); here an odd count is handled by a

@@ -47,6 +47,7 @@ class Oracle:
             "fo_add_source": (None, [i, f, _F, _F]),
             "fo_jacobi_sweep": (None, [i, i, _F, _F, _F, f, f]),
             "fo_diffuse": (i, [i, i, _F, _F, f, f, i]),
+            "fo_jacobi_rows": (None, [i, _F, _F, _F, f, f, i, i]),
             "fo_advect": (None, [i, i, f, _F, _F, _F, _F]),
             "fo_divergence": (None, [i, _F, _F, _F, _F]),
             "fo_subtract_gradient": (None, [i, _F, _F, _F]),
@@ -75,6 +76,22 @@ class Oracle:
 
     def jacobi_sweep(self, b, x, x0, out, alpha, beta):
         self.lib.fo_jacobi_sweep(self._n(x), b, x, x0, out, alpha, beta)
+
+    def diffuse_threaded(self, b, x, x0, alpha, beta, iters, threads):
+        """The same solve with every sweep split into row bands over `threads`
+        host threads (ctypes releases the GIL); bit-identical to diffuse()."""
+        from concurrent.futures import ThreadPoolExecutor
+        n = self._n(x)
+        edges = [1 + (n * k) // threads for k in range(threads + 1)]
+        cur, nxt = x, np.empty_like(x)
+        with ThreadPoolExecutor(threads) as pool:
+            for _ in range(iters):
+                list(pool.map(lambda k: self.lib.fo_jacobi_rows(n, cur, x0, nxt, alpha, beta, edges[k], edges[k + 1]),
+                              range(threads)))
+                self.lib.fo_set_bnd(n, b, nxt)
+                cur, nxt = nxt, cur
+        if cur is not x:
+            x[...] = cur
 
     def diffuse(self, b, x, x0, alpha, beta, iters=ITERS):
         assert self.lib.fo_diffuse(self._n(x), b, x, x0, alpha, beta, iters) == 0

@@ -1,0 +1,118 @@
+"""CPU parts of the harness (input recipe, report format) + GPU: state round trip,
+per-operator timing, tolerance-terminated solve."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal, rnd
+
+
+def test_initialize_parameters_recipe():
+    """FluidSequential.c:244-271: density k/1000 only inside the centred square of
+    half-width (N+2)/8, velocity sources k/100 everywhere, current fields zero."""
+    from fluidsimulationcuda_amd.harness import initialize_parameters
+    n = 62
+    f = initialize_parameters(n, seed=3)
+    w, c, r = n + 2, (n + 2) // 2, (n + 2) // 8
+    mask = np.zeros((w, w), bool)
+    mask[c - r:c + r, c - r:c + r] = True
+    assert (f["dens_prev"][~mask] == 0).all() and 0 < f["dens_prev"][mask].max() < 0.1
+    assert not f["u"].any() and not f["v"].any() and not f["dens"].any()
+    for name in ("u_prev", "v_prev"):
+        k = np.rint(f[name] * 100)
+        assert np.array_equal((k / 100.0).astype(np.float32), f[name]) and k.min() >= 0 and k.max() <= 99
+    g = initialize_parameters(n, seed=3)
+    assert all(np.array_equal(f[k], g[k]) for k in f)
+    assert not np.array_equal(initialize_parameters(n, seed=4)["u_prev"], f["u_prev"])
+
+
+def test_report_format_matches_reference_printf():
+    from fluidsimulationcuda_amd.harness import format_report
+    txt = format_report(dict(Tot=1.5, Source=0.25, Diffusion=0.125, Divergence=2, Advection=3, Projection=4))
+    assert txt == "Tot 1.500000\nSource 0.250000\nDiffusion 0.125000\nDivergence 2.000000\nAdvection 3.000000\nProjection 4.000000\n"
+
+
+def test_print_state_grid_layout():
+    from fluidsimulationcuda_amd.harness import print_state_grid
+    d = np.array([[1, 2], [3, 4]], np.float32)
+    buf = io.StringIO()
+    print_state_grid(d, d * 10, d * 100, out=buf)
+    lines = buf.getvalue().splitlines()
+    assert lines[1] == "DENSITY" and lines[2] == "[1.000000] [2.000000] "
+    assert "VELOCITY" in lines and lines[-1] == "[30.000000, 300.000000] [40.000000, 400.000000] "
+
+
+def test_threaded_oracle_sweeps_match(oracle):
+    rng = np.random.default_rng(8)
+    x, x0 = rnd(rng, 97), rnd(rng, 97)
+    a, b = x.copy(), x.copy()
+    oracle.diffuse(2, a, x0, 0.4, 2.6, 6)
+    oracle.diffuse_threaded(2, b, x0, 0.4, 2.6, 6, threads=5)
+    assert_bit_equal(b, a, "row-band threaded sweeps")
+
+
+@pytest.mark.gpu
+def test_state_round_trip(tmp_path):
+    import fluidsimulationcuda_amd as F
+    from fluidsimulationcuda_amd.harness import initialize_parameters, load_state, save_state
+    n = 126
+    path = os.path.join(tmp_path, "state.f32")
+    with F.FluidSolver(n) as s:
+        s.upload(**initialize_parameters(n))
+        s.step(1, use_sources=True)
+        s.step(1)
+        save_state(s, path, step_index=2)
+        s.step(2)
+        want = {k: s.download(k) for k in ("u", "v", "dens")}
+    assert os.path.getsize(path) == 8 + 8 + 6 * 128 * 128 * 4
+    with F.FluidSolver(n) as s:
+        assert load_state(s, path) == 2
+        s.step(2)
+        for k in want:
+            assert_bit_equal(s.download(k), want[k], "resume from dump: " + k)
+    with F.FluidSolver(30) as s, pytest.raises(ValueError):
+        load_state(s, path)
+
+
+@pytest.mark.gpu
+def test_timing_categories_count_every_operator():
+    import fluidsimulationcuda_amd as F
+    from fluidsimulationcuda_amd.harness import initialize_parameters, run_steps
+    n = 254
+    with F.FluidSolver(n) as s:
+        s.upload(**initialize_parameters(n))
+        s.timing_enable(True)
+        s.step(1, use_sources=True)
+        s.step(2)
+        t = s.timing_read()
+        # per step: 3 add_source, 5 solves (200 sweeps), 2 divergence, 2 gradient, 3 advect
+        assert (t["source_calls"], t["solves"], t["sweeps"]) == (9, 15, 600)
+        assert (t["divergence_calls"], t["projection_calls"], t["advection_calls"]) == (6, 6, 9)
+        assert all(t[k + "_ms"] > 0 for k in ("source", "diffusion", "divergence", "projection", "advection"))
+        s.timing_enable(False)
+        r = run_steps(s, 3, first_uses_sources=False)
+        assert r["sweeps"] == 600 and 0 < r["Diffusion"] < r["Tot"]
+
+
+@pytest.mark.gpu
+def test_tolerance_terminated_solve_is_opt_in_extension():
+    import fluidsimulationcuda_amd as F
+    n = 126
+    rng = np.random.default_rng(1)
+    x0 = rnd(rng, n)
+    with F.FluidSolver(n) as s:
+        s.upload(v=x0)
+        s.fill("u", 0.0)
+        a, b = F.coefficients(n, 0.016, 0.0025)
+        r0 = s.residual("u", "v", a, b)
+        its, res = s.diffuse_tol(0, "u", "v", a, b, tol=r0 * 1e-4, max_iters=4000, check_every=8)
+        assert 0 < its < 4000 and its % 8 == 0 and res <= r0 * 1e-4
+        # the same number of plain sweeps gives the same field
+        got = s.download("u")
+        s.fill("u", 0.0)
+        s.diffuse(0, "u", "v", a, b, its)
+        assert_bit_equal(s.download("u"), got, "diffuse_tol == diffuse(iters done)")
+        its2, _ = s.diffuse_tol(0, "u", "v", a, b, tol=1e30)
+        assert its2 == 0                                   # already converged: no sweeps
