@@ -14,7 +14,7 @@ OK, E_INVALID, E_NOMEM, E_HIP, E_COMM = 0, 1, 2, 3, 4
 U, V, DENS, U_PREV, V_PREV, DENS_PREV, TMP0, TMP1, TMP2 = range(9)
 NFIELDS = 9
 JACOBI_STREAM, JACOBI_LDS, JACOBI_NAIVE, JACOBI_TB = 0, 1, 2, 3
-PARAM_TB_MAX_SWEEPS, PARAM_TB_ROWS, PARAM_HALO, PARAM_TB_FAST_DIVISION = 0, 1, 2, 3
+PARAM_TB_MAX_SWEEPS, PARAM_TB_ROWS, PARAM_HALO, PARAM_TB_FAST_DIVISION, PARAM_TB_MIN_CELLS = 0, 1, 2, 3, 4
 XCHG_HALO, XCHG_GATHER, XCHG_MAX = 0, 1, 2
 FIELD_NAMES = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev", "tmp0", "tmp1", "tmp2")
 

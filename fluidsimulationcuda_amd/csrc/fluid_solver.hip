@@ -63,6 +63,7 @@ struct fluid_ctx {
     unsigned int* h_scalar = nullptr;     // pinned host mirror
     int variant = fluid::JACOBI_TB;
     int tb_max_t = 8, tb_rows = 0, num_cu = 256;   // temporal blocking: sweeps/launch cap, rows/strip (0 = auto)
+    long long tb_min_cells = 1500000;              // smaller slabs use single-sweep launches
     bool fast_div = true;                          // allow division modes 1/2 (each beta proven on the device first)
     std::unordered_map<unsigned, int> div_mode;    // beta bits -> proven division mode
     // slab decomposition
@@ -293,12 +294,16 @@ int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int 
         }
         const int room = std::min(r, remaining);
         int T = 1;
-        if (c->variant == fluid::JACOBI_TB)
+        // below ~1.5M cells per slab a sweep is bound by launch latency, not bytes: the 256-column
+        // windows of the blocked kernel cannot fill 256 CUs and one thread per cell is fastest
+        // (measured crossover ~1300^2, profiles/r01_config1_1024.md)
+        const bool small = (long long)(c->own1 - c->own0) * c->n < c->tb_min_cells;
+        if (c->variant == fluid::JACOBI_TB && !small)
             T = (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
         int lo, hi;
         rows(c, multi ? std::min(r - T, exchange_cap(c)) : 0, &lo, &hi);
         if (T == 1) {
-            const int v = c->variant == fluid::JACOBI_TB ? fluid::JACOBI_STREAM : c->variant;
+            const int v = c->variant == fluid::JACOBI_TB ? (small ? fluid::JACOBI_NAIVE : fluid::JACOBI_STREAM) : c->variant;
             fluid::launch_jacobi(c->stream, v, c->f[cur], c->f[x0], c->f[nxt], c->pitch, c->n, lo, hi, alpha, beta, b);
         } else {
             int rb = c->tb_rows;
@@ -727,6 +732,10 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
     case FLUID_PARAM_TB_ROWS:
         if (value < 0) return fail(FLUID_E_INVALID, "TB_ROWS must be >= 0");
         c->tb_rows = value;
+        return FLUID_OK;
+    case FLUID_PARAM_TB_MIN_CELLS:
+        if (value < 0) return fail(FLUID_E_INVALID, "TB_MIN_CELLS must be >= 0");
+        c->tb_min_cells = value;
         return FLUID_OK;
     case FLUID_PARAM_TB_FAST_DIVISION:
         c->fast_div = value != 0;

@@ -35,7 +35,7 @@ class FluidSolver:
     """Six resident fields + scratch on one GPU (or one row slab of several)."""
 
     def __init__(self, n, rank=0, nranks=1, halo=0, jacobi=capi.JACOBI_TB, stream=None,
-                 arena_ptr=None, arena_bytes=0):
+                 arena_ptr=None, arena_bytes=0, params=None):
         self._h = C.c_void_p()
         self.n = int(n)
         cfg = capi.Config(n=self.n, rank=rank, nranks=nranks, halo=halo, jacobi_variant=jacobi,
@@ -46,6 +46,8 @@ class FluidSolver:
         self.owned_rows = (lo.value, hi.value)
         self.rank, self.nranks = rank, nranks
         self._cb = None
+        for key, value in (params or {}).items():     # capi.PARAM_* tuning knobs
+            self.set_param(key, value)
 
     # -- lifetime
     def close(self):

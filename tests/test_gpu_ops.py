@@ -49,7 +49,7 @@ def test_add_source(F, oracle, n):
 @pytest.mark.parametrize("n", SIZES)
 def test_jacobi_single_sweep(F, oracle, n, variant):
     rng = np.random.default_rng(100 + n)
-    with F.FluidSolver(n, jacobi=variant) as s:
+    with F.FluidSolver(n, jacobi=variant, params={4: 0}) as s:
         for b, (alpha, beta) in ((0, (1.0, 4.0)), (1, F.coefficients(n, DT, VISC)), (2, F.coefficients(n, DT, DIFF))):
             x, x0, stale = rnd(rng, n), rnd(rng, n), rnd(rng, n)
             s.upload(u=x, v=x0, dens=stale)
@@ -64,7 +64,7 @@ def test_jacobi_single_sweep(F, oracle, n, variant):
 @pytest.mark.parametrize("n", [3, 30, 126, 257])
 def test_diffuse_40(F, oracle, n, variant):
     rng = np.random.default_rng(200 + n)
-    with F.FluidSolver(n, jacobi=variant) as s:
+    with F.FluidSolver(n, jacobi=variant, params={4: 0}) as s:
         for b, coef in ((1, VISC), (2, VISC), (0, DIFF), (0, None)):
             alpha, beta = (1.0, 4.0) if coef is None else F.coefficients(n, DT, coef)
             x, x0 = rnd(rng, n), rnd(rng, n)
@@ -215,6 +215,7 @@ def test_temporal_blocking_matches_oracle(F, oracle, n, max_t):
     from fluidsimulationcuda_amd import capi
     rng = np.random.default_rng(500 + n)
     with F.FluidSolver(n, jacobi=capi.JACOBI_TB) as s:
+        s.set_param(capi.PARAM_TB_MIN_CELLS, 0)              # fuse sweeps even on these small grids
         s.set_param(capi.PARAM_TB_MAX_SWEEPS, max_t)
         for rows in (0, 1, 3, 16, 5000):
             s.set_param(capi.PARAM_TB_ROWS, rows)
@@ -237,6 +238,7 @@ def test_temporal_blocking_power_of_two_beta_paths(F, oracle):
     n = 61
     rng = np.random.default_rng(77)
     with F.FluidSolver(n, jacobi=capi.JACOBI_TB) as s:
+        s.set_param(capi.PARAM_TB_MIN_CELLS, 0)
         for beta in (4.0, 0.5, 1.0, 1024.0, 2.0 ** -20, 2.0 ** 100):
             for scale in (1.0, 1e-38, 1e30):
                 x, x0 = rnd(rng, n) * np.float32(scale), rnd(rng, n) * np.float32(scale)
@@ -260,6 +262,7 @@ def test_temporal_blocking_reciprocal_division_is_exact(F, oracle, beta):
     specials = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-39, -3e-39, 1.17549435e-38, 3e38, -3e38, 1e-30, 6e-45, 9e-45],
                         dtype=np.float32)
     with F.FluidSolver(n, jacobi=capi.JACOBI_TB) as s:
+        s.set_param(capi.PARAM_TB_MIN_CELLS, 0)
         for fast in (1, 0):
             s.set_param(capi.PARAM_TB_FAST_DIVISION, fast)
             for kind in ("uniform", "special", "tiny"):

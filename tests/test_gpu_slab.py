@@ -120,7 +120,8 @@ def _init_fake(s, n, rank, nranks, halo, jacobi):
     torch.cuda.synchronize()
     FluidSolver.__init__(s, n, rank=rank, nranks=nranks, halo=halo, jacobi=jacobi,
                          stream=s.torch_stream.cuda_stream,
-                         arena_ptr=s.arena.data_ptr(), arena_bytes=nbytes)
+                         arena_ptr=s.arena.data_ptr(), arena_bytes=nbytes,
+                         params={capi.PARAM_TB_MIN_CELLS: 0})     # fuse sweeps even on these small slabs
     s._ff = ff.value
     s._views = [s.arena[k * ff.value:(k + 1) * ff.value].view(n + 2, s.pitch) for k in range(capi.NFIELDS)]
     s.exchange = None
