@@ -17,8 +17,18 @@ void launch_set_bnd(hipStream_t s, float* f, int pitch, int n, int b);
 void launch_add_source(hipStream_t s, float* x, const float* src, int pitch, int row_lo, int row_hi, float dt);
 void launch_jacobi(hipStream_t s, int variant, const float* x, const float* x0, float* out, int pitch, int n,
                    int row_lo, int row_hi, float alpha, float beta, int b);
-void launch_jacobi_tb(hipStream_t s, int T, int divmode, const float* x, const float* x0, float* out, int pitch,
-                      int n, int row_lo, int row_hi, int rb, float alpha, float beta, double yd, int b);
+// up to three independent solves of the same shape, one per blockIdx.z of the fused Jacobi kernel
+struct TbBatch {
+    const float* x[3];
+    const float* x0[3];
+    float* out[3];
+    float alpha[3], beta[3];     // beta: divisor, or its exact reciprocal in division mode 1
+    double yd[3];                // RN64(1/beta) for division mode 2
+    int b[3];
+    int count;
+};
+void launch_jacobi_tb(hipStream_t s, int T, int divmode, const TbBatch& batch, int pitch, int n, int row_lo,
+                      int row_hi, int rb);
 void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, double yd, unsigned long long* bad);
 void launch_advect(hipStream_t s, float* d, const float* d0, const float* u, const float* v, int pitch, int n,
                    int row_lo, int row_hi, float dt0, int b);

@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void k_jacobi_stream(const float* __restrict__
 // output rows, marching down the rows with all T sweeps in flight: at step t it
 // loads row t of x and x0 and, for s = 1..T, produces row t-s of "x after s
 // sweeps" from the three rows of stage s-1 it still holds.  Everything lives in
-// registers: per stage a three-row ring of its input, and a queue of the last T
-// x0 rows.  The time loop is unrolled by three so the rings rotate by renaming,
+// registers: per stage a three-row ring of its input, a queue of the last T x0
+// rows, and three rows of x/x0 prefetched ahead of use.  The time loop is unrolled by three so the rings rotate by renaming,
 // not by moving.  Left/right neighbours come from the adjacent lanes by DPP; a
 // wave has no one to ask at its two ends, so windows overlap by HL = ceil(T/4)
 // lanes per side and only the inner 64-2*HL lanes store (the wrong values creep
@@ -464,15 +464,15 @@ __device__ __forceinline__ void tb_qshift(float4 (&Q)[N])
 // stage needs is interior -- a branch-free body.  WALL = true: per-stage checks,
 // ghost rows of each stage regenerated from its rows 1 / n.
 template <int T, int DIVMODE, bool EDGE, bool WALL, int PH>
-__device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T + 1], float4& nx, float4& nq,
+__device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T + 1], float4 (&PX)[3], float4 (&PQ)[3],
                                         const TbArgs& a)
 {
     constexpr int UP = PH % 3, ME = (PH + 1) % 3, FR = (PH + 2) % 3;
-    W[0][FR] = nx;                                       // stage 0: row t of x
-    Q[0] = nq;
-    if (t < a.t_ld && a.ld_ok) {                         // prefetch row t+1 under this step's arithmetic
-        nx = *reinterpret_cast<const float4*>(a.xc + (size_t)(t + 1) * a.P);
-        nq = *reinterpret_cast<const float4*>(a.rc + (size_t)(t + 1) * a.P);
+    W[0][FR] = PX[PH];                                   // stage 0: row t of x (loaded three steps ago)
+    Q[0] = PQ[PH];
+    if (t + 3 <= a.t_ld && a.ld_ok) {                    // refill the slot with row t+3: three steps of
+        PX[PH] = *reinterpret_cast<const float4*>(a.xc + (size_t)(t + 3) * a.P);   // arithmetic cover the
+        PQ[PH] = *reinterpret_cast<const float4*>(a.rc + (size_t)(t + 3) * a.P);   // HBM latency
     }
 #pragma unroll
     for (int s = 1; s <= T; ++s) {
@@ -507,28 +507,44 @@ __device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T 
 }
 
 template <int T, int DIVMODE, bool EDGE, bool WALL>
-__device__ __forceinline__ void tb_march(int t0, int t1, float4 nx, float4 nq, const TbArgs& a)
+__device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs& a)
 {
-    float4 W[T][3], Q[T + 1];
+    float4 W[T][3], Q[T + 1], PX[3], PQ[3];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int s = 0; s < T; ++s) { W[s][0] = zero4; W[s][1] = zero4; W[s][2] = zero4; }
 #pragma unroll
     for (int s = 0; s <= T; ++s) Q[s] = zero4;
-    // whole triples only: up to two surplus steps load nothing (t >= t_ld) and store nothing (q >= q_hi)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {                        // rows t0, t0+1, t0+2 in flight before the first step
+        PX[d] = zero4;
+        PQ[d] = zero4;
+        if (t0 + d <= a.t_ld && a.ld_ok) {
+            PX[d] = *reinterpret_cast<const float4*>(a.xc + (size_t)(t0 + d) * a.P);
+            PQ[d] = *reinterpret_cast<const float4*>(a.rc + (size_t)(t0 + d) * a.P);
+        }
+    }
+    // whole triples only: up to two surplus steps load nothing (t > t_ld) and store nothing (q >= q_hi)
     for (int t = t0; t <= t1; t += 3) {
-        tb_step<T, DIVMODE, EDGE, WALL, 0>(t, W, Q, nx, nq, a);
-        tb_step<T, DIVMODE, EDGE, WALL, 1>(t + 1, W, Q, nx, nq, a);
-        tb_step<T, DIVMODE, EDGE, WALL, 2>(t + 2, W, Q, nx, nq, a);
+        tb_step<T, DIVMODE, EDGE, WALL, 0>(t, W, Q, PX, PQ, a);
+        tb_step<T, DIVMODE, EDGE, WALL, 1>(t + 1, W, Q, PX, PQ, a);
+        tb_step<T, DIVMODE, EDGE, WALL, 2>(t + 2, W, Q, PX, PQ, a);
     }
 }
 
-// second launch-bound argument = waves per SIMD the register allocator must leave room for
+// second launch-bound argument = waves per SIMD the register allocator must leave room for.
+// blockIdx.z picks one of up to three independent solves of the same shape (u, v and density
+// diffusion): more waves per launch, hence taller strips and less pipeline-fill redundancy.
 template <int T, int DIVMODE>
-__global__ __launch_bounds__(256, (T <= 4 ? 4 : 2)) void k_jacobi_tb(const float* __restrict__ x, const float* __restrict__ x0,
-                                                   float* __restrict__ out, int pitch, int n, int row_lo,
-                                                   int row_hi, int rb, float alpha, float beta, double yd, int b)
+__global__ __launch_bounds__(256, (T <= 4 ? 3 : 2)) void k_jacobi_tb(TbBatch batch, int pitch, int n, int row_lo, int row_hi,
+                                                                    int rb)
 {
+    const float* __restrict__ x = batch.x[blockIdx.z];
+    const float* __restrict__ x0 = batch.x0[blockIdx.z];
+    float* __restrict__ out = batch.out[blockIdx.z];
+    const float alpha = batch.alpha[blockIdx.z], beta = batch.beta[blockIdx.z];
+    const double yd = batch.yd[blockIdx.z];
+    const int b = batch.b[blockIdx.z];
     constexpr int HL = (T + 3) / 4;
     constexpr int VS = 64 - 2 * HL;
     const int lane = threadIdx.x & 63;
@@ -564,20 +580,15 @@ __global__ __launch_bounds__(256, (T <= 4 ? 4 : 2)) void k_jacobi_tb(const float
     a.beta = beta;
     const int t0 = max(0, a.q_lo - T), t1 = a.q_hi - 1 + T;
     a.t_ld = min(t1, n + 1);                             // last row that exists
-    float4 nx = make_float4(0.f, 0.f, 0.f, 0.f), nq = nx;
-    if (a.ld_ok) {
-        nx = *reinterpret_cast<const float4*>(a.xc + (size_t)t0 * a.P);
-        nq = *reinterpret_cast<const float4*>(a.rc + (size_t)t0 * a.P);
-    }
     // a strip whose input rows [q_lo-T, q_hi-1+T] all exist never needs a regenerated ghost row
     const bool wall = (a.q_lo < T) || (a.q_hi - 1 + T > n + 1);      // wave-uniform
     const bool edge = a.left_edge || a.right_edge;                   // wave-uniform
     if (edge) {
-        if (wall) tb_march<T, DIVMODE, true, true>(t0, t1, nx, nq, a);
-        else      tb_march<T, DIVMODE, true, false>(t0, t1, nx, nq, a);
+        if (wall) tb_march<T, DIVMODE, true, true>(t0, t1, a);
+        else      tb_march<T, DIVMODE, true, false>(t0, t1, a);
     } else {
-        if (wall) tb_march<T, DIVMODE, false, true>(t0, t1, nx, nq, a);
-        else      tb_march<T, DIVMODE, false, false>(t0, t1, nx, nq, a);
+        if (wall) tb_march<T, DIVMODE, false, true>(t0, t1, a);
+        else      tb_march<T, DIVMODE, false, false>(t0, t1, a);
     }
 }
 
@@ -747,17 +758,17 @@ void launch_jacobi(hipStream_t s, int variant, const float* x, const float* x0, 
     }
 }
 
-// T in {8,4,2}.  divmode 0: beta; 1: beta = exact reciprocal; 2: beta unused, yd = RN64(1/beta).
-void launch_jacobi_tb(hipStream_t s, int T, int divmode, const float* x, const float* x0, float* out, int pitch,
-                      int n, int row_lo, int row_hi, int rb, float alpha, float beta, double yd, int b)
+// T in {8,4,2}; batch.count solves per launch.  divmode 0: beta; 1: beta = exact reciprocal;
+// 2: beta unused, yd = RN64(1/beta).
+void launch_jacobi_tb(hipStream_t s, int T, int divmode, const TbBatch& batch, int pitch, int n, int row_lo,
+                      int row_hi, int rb)
 {
     const int rows = row_hi - row_lo;
-    if (rows <= 0) return;
+    if (rows <= 0 || batch.count <= 0) return;
     const int HL = (T + 3) / 4, VS = 64 - 2 * HL;
     const unsigned nvec = (n + 3) / 4;
-    const dim3 grid(cdiv(nvec, VS), cdiv(cdiv(rows, rb), 4)), block(256);
-#define FLUID_TB1(TT, DD) \
-    hipLaunchKernelGGL((k_jacobi_tb<TT, DD>), grid, block, 0, s, x, x0, out, pitch, n, row_lo, row_hi, rb, alpha, beta, yd, b)
+    const dim3 grid(cdiv(nvec, VS), cdiv(cdiv(rows, rb), 4), batch.count), block(256);
+#define FLUID_TB1(TT, DD) hipLaunchKernelGGL((k_jacobi_tb<TT, DD>), grid, block, 0, s, batch, pitch, n, row_lo, row_hi, rb)
 #define FLUID_TB(TT)                     \
     if (divmode == 2) FLUID_TB1(TT, 2);  \
     else if (divmode == 1) FLUID_TB1(TT, 1); \

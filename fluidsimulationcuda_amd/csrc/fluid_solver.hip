@@ -223,7 +223,7 @@ int exchange_cap(const fluid_ctx* c) { return c->min_slab - 1; }     // rows a n
 
 void wrote(fluid_ctx* c, int f, int reach) { c->reach[f] = c->nranks > 1 ? reach : kEverywhere; }
 
-int need(fluid_ctx* c, std::initializer_list<int> fields, int reach)
+int need_list(fluid_ctx* c, const std::vector<int>& fields, int reach)
 {
     if (c->nranks == 1 || reach <= 0) return FLUID_OK;
     if (reach > exchange_cap(c)) return fail(FLUID_E_COMM, "halo of %d rows exceeds the slab height", reach);
@@ -238,6 +238,11 @@ int need(fluid_ctx* c, std::initializer_list<int> fields, int reach)
     if (rc != 0) return fail(FLUID_E_COMM, "halo exchange failed (rc %d)", rc);
     for (int f : ids) c->reach[f] = reach;
     return FLUID_OK;
+}
+
+int need(fluid_ctx* c, std::initializer_list<int> fields, int reach)
+{
+    return need_list(c, std::vector<int>(fields), reach);
 }
 
 // interior rows [lo,hi) this slab computes when it works `reach` rows past its inner edges
@@ -261,78 +266,140 @@ int op_add_source(fluid_ctx* c, int x, int s, float dt)
     return FLUID_OK;
 }
 
-// FluidSequential.c:85-104.  Result lands in field x.  A sweep that writes `r`
-// rows past the slab needs x valid r+1 rows out and x0 r rows out, so a solve
+// One Jacobi solve of the step: field x (first guess in, result out), right-hand
+// side x0, wall rule b.  Up to three such solves of the same length run as one
+// batch (u, v and density diffusion are independent of one another).
+struct Solve {
+    int b, x, x0;
+    float alpha, beta;
+};
+
+// FluidSequential.c:85-104.  Results land in the fields `x`.  A sweep that writes
+// `r` rows past the slab needs x valid r+1 rows out and x0 r rows out, so a solve
 // that starts with reach R runs R sweeps before it must exchange again -- on
 // ranges that shrink one row per sweep per inner edge, the same arithmetic per
 // cell as the 1-GPU run (bit-identical).  `final_reach`: rows past the slab the
 // caller would like valid afterwards (the gradient wants 1).  The temporally
-// blocked kernel runs T of the sweeps per launch.  Sweeps ping-pong between x's
-// buffer and TMP0's; if the result ends in TMP0's buffer the two fields trade
-// buffers (pointer swap, no copy) -- field ids, not addresses, are stable.
-int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int iters, int final_reach = 0)
+// blocked kernel runs T of the sweeps per launch, all solves of the batch in the
+// same launch.  Sweeps ping-pong between x's buffer and a scratch field's; if a
+// result ends in the scratch buffer the two fields trade buffers (pointer swap,
+// no copy) -- field ids, not addresses, are stable.
+int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int final_reach = 0)
 {
+    static const int kScratch[3] = {FLUID_TMP0, FLUID_TMP1, FLUID_TMP2};
     if (iters < 0 || (iters & 1)) return fail(FLUID_E_INVALID, "sweep count must be even and >= 0 (got %d)", iters);
-    if (x == x0 || x == FLUID_TMP0 || x0 == FLUID_TMP0)
-        return fail(FLUID_E_INVALID, "diffuse: x, x0 and TMP0 must be distinct fields");
+    if (count < 1 || count > 3) return fail(FLUID_E_INVALID, "a batch holds 1 to 3 solves");
+    for (int k = 0; k < count; ++k) {
+        if (sv[k].x == sv[k].x0 || sv[k].x >= FLUID_TMP0 || sv[k].x0 >= FLUID_TMP0)
+            return fail(FLUID_E_INVALID, "diffuse: x and x0 must be distinct non-scratch fields");
+        for (int j = 0; j < k; ++j)
+            if (sv[j].x == sv[k].x || sv[j].x == sv[k].x0 || sv[j].x0 == sv[k].x)
+                return fail(FLUID_E_INVALID, "diffuse: the solves of a batch must not share fields");
+    }
     if (iters == 0) return FLUID_OK;
     hipEvent_t stop;
     TRY(timing_begin(c, FLUID_TIME_DIFFUSION, &stop));
-    int cur = x, nxt = FLUID_TMP0;
     const bool multi = c->nranks > 1;
-    float div_arg = beta;
-    double yd = 0.0;
-    const int divmode = c->variant == fluid::JACOBI_TB ? division_mode(c, beta, &div_arg, &yd) : 0;
-    int r = multi ? std::min(c->reach[x], c->reach[x0] + 1) : kEverywhere;    // sweeps possible right now
+    int cur[3], nxt[3], divmode[3];
+    float div_arg[3];
+    double yd[3];
+    bool same_mode = true;
+    for (int k = 0; k < count; ++k) {
+        cur[k] = sv[k].x;
+        nxt[k] = kScratch[k];
+        div_arg[k] = sv[k].beta;
+        yd[k] = 0.0;
+        divmode[k] = c->variant == fluid::JACOBI_TB ? division_mode(c, sv[k].beta, &div_arg[k], &yd[k]) : 0;
+        same_mode = same_mode && divmode[k] == divmode[0];
+    }
+    auto reach_now = [&]() {
+        int r = kEverywhere;
+        for (int k = 0; k < count; ++k) r = std::min(r, std::min(c->reach[cur[k]], c->reach[sv[k].x0] + 1));
+        return r;
+    };
+    int r = multi ? reach_now() : kEverywhere;            // sweeps possible right now
+    // below ~1.5M cells per slab a sweep is bound by launch latency, not bytes: the 256-column
+    // windows of the blocked kernel cannot fill 256 CUs and one thread per cell is fastest
+    // (measured crossover ~1300^2, profiles/r01_config1_1024.md)
+    const bool small = (long long)(c->own1 - c->own0) * c->n * count < c->tb_min_cells;
     for (int k = 0; k < iters;) {
         const int remaining = iters - k;
         if (r < 1) {
             const int depth = std::max(1, std::min(c->halo, remaining + final_reach));
-            if (c->reach[x0] < depth - 1) TRY(need(c, {cur, x0}, depth));
-            else TRY(need(c, {cur}, depth));
-            r = std::min(c->reach[cur], c->reach[x0] + 1);
+            std::vector<int> ids;
+            for (int j = 0; j < count; ++j) {
+                ids.push_back(cur[j]);
+                if (c->reach[sv[j].x0] < depth - 1) ids.push_back(sv[j].x0);
+            }
+            TRY(need_list(c, ids, depth));
+            r = reach_now();
         }
         const int room = std::min(r, remaining);
         int T = 1;
-        // below ~1.5M cells per slab a sweep is bound by launch latency, not bytes: the 256-column
-        // windows of the blocked kernel cannot fill 256 CUs and one thread per cell is fastest
-        // (measured crossover ~1300^2, profiles/r01_config1_1024.md)
-        const bool small = (long long)(c->own1 - c->own0) * c->n < c->tb_min_cells;
         if (c->variant == fluid::JACOBI_TB && !small)
             T = (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
         int lo, hi;
         rows(c, multi ? std::min(r - T, exchange_cap(c)) : 0, &lo, &hi);
         if (T == 1) {
             const int v = c->variant == fluid::JACOBI_TB ? (small ? fluid::JACOBI_NAIVE : fluid::JACOBI_STREAM) : c->variant;
-            fluid::launch_jacobi(c->stream, v, c->f[cur], c->f[x0], c->f[nxt], c->pitch, c->n, lo, hi, alpha, beta, b);
+            for (int j = 0; j < count; ++j)
+                fluid::launch_jacobi(c->stream, v, c->f[cur[j]], c->f[sv[j].x0], c->f[nxt[j]], c->pitch, c->n, lo, hi,
+                                     sv[j].alpha, sv[j].beta, sv[j].b);
         } else {
-            int rb = c->tb_rows;
-            if (rb <= 0) {
-                // auto (tools/tb_sweep.py on MI355X, 4096^2 and 8192^2): the register-heavy T=8 kernel
-                // holds 2 waves per SIMD and likes one full round of them; T<=4 holds 4 and peaks
-                // near 2.8.  Longer strips amortise the 2T-row pipeline fill, shorter ones feed more
-                // SIMDs; past ~80-96 rows the fill is already < 20 % and more strips win.
-                const int HL = (T + 3) / 4, VS = 64 - 2 * HL;
-                const long long windows = ((c->n + 3) / 4 + VS - 1) / VS;
-                const long long want = (long long)c->num_cu * 4 * (T >= 8 ? 19 : 28) / 10;
-                rb = (int)(((long long)(hi - lo) * windows + want - 1) / want);
-                rb = std::max(2 * T, std::min(rb, T >= 8 ? 80 : 96));
+            // one launch per group of solves that share a division mode (normally: all of them)
+            for (int first = 0; first < count;) {
+                fluid::TbBatch bt{};
+                int m = 0;
+                int last = first;
+                for (int j = first; j < count && (same_mode || j == first); ++j, ++last) {
+                    bt.x[m] = c->f[cur[j]];
+                    bt.x0[m] = c->f[sv[j].x0];
+                    bt.out[m] = c->f[nxt[j]];
+                    bt.alpha[m] = sv[j].alpha;
+                    bt.beta[m] = div_arg[j];
+                    bt.yd[m] = yd[j];
+                    bt.b[m] = sv[j].b;
+                    ++m;
+                }
+                bt.count = m;
+                int rb = c->tb_rows;
+                if (rb <= 0) {
+                    // auto (tools/tb_sweep.py on MI355X, 4096^2 and 8192^2): the register-heavy T=8 kernel
+                    // holds 2 waves per SIMD and likes one full round of them; T<=4 holds 3 and peaks
+                    // near 2.8.  Longer strips amortise the 2T-row pipeline fill, shorter ones feed more
+                    // SIMDs; a batch of solves multiplies the waves, so its strips can be that much taller.
+                    const int HL = (T + 3) / 4, VS = 64 - 2 * HL;
+                    const long long windows = ((c->n + 3) / 4 + VS - 1) / VS;
+                    const long long want = (long long)c->num_cu * 4 * (T >= 8 ? 19 : 28) / 10;
+                    rb = (int)(((long long)(hi - lo) * windows * m + want - 1) / want);
+                    rb = std::max(2 * T, std::min(rb, T >= 8 ? 160 : 192));
+                }
+                fluid::launch_jacobi_tb(c->stream, T, divmode[first], bt, c->pitch, c->n, lo, hi, rb);
+                first = last;
             }
-            fluid::launch_jacobi_tb(c->stream, T, divmode, c->f[cur], c->f[x0], c->f[nxt], c->pitch, c->n, lo, hi, rb,
-                                    alpha, div_arg, yd, b);
         }
         r = multi ? std::min(r - T, exchange_cap(c)) : kEverywhere;
-        wrote(c, nxt, r);
-        std::swap(cur, nxt);
+        for (int j = 0; j < count; ++j) {
+            wrote(c, nxt[j], r);
+            std::swap(cur[j], nxt[j]);
+        }
         k += T;
     }
     HIP_TRY(hipGetLastError());
-    if (cur != x) {
-        std::swap(c->f[x], c->f[FLUID_TMP0]);
-        std::swap(c->reach[x], c->reach[FLUID_TMP0]);
+    for (int j = 0; j < count; ++j) {
+        if (cur[j] != sv[j].x) {
+            std::swap(c->f[sv[j].x], c->f[kScratch[j]]);
+            std::swap(c->reach[sv[j].x], c->reach[kScratch[j]]);
+        }
+        wrote(c, kScratch[j], 0);
     }
-    wrote(c, FLUID_TMP0, 0);
-    return timing_end(c, stop, iters);
+    return timing_end(c, stop, iters * count);
+}
+
+int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int iters, int final_reach = 0)
+{
+    const Solve one{b, x, x0, alpha, beta};
+    return op_diffuse_batch(c, &one, 1, iters, final_reach);
 }
 
 // FluidSequential.c:107-141.  The back-trace reaches dt0*max|vel| cells, so a
@@ -437,8 +504,8 @@ int vel_step(fluid_ctx* c, float dt, float visc, int iters)
     // one exchange feeds both solves: right-hand sides iters-1 rows out, first guesses iters rows
     const int h = std::min(iters, c->halo);
     TRY(need(c, {U, V, U0, V0}, h));
-    TRY(op_diffuse(c, 1, U0, U, alpha, beta, iters));
-    TRY(op_diffuse(c, 2, V0, V, alpha, beta, iters));
+    const Solve uv[2] = {{1, U0, U, alpha, beta}, {2, V0, V, alpha, beta}};
+    TRY(op_diffuse_batch(c, uv, 2, iters));
     TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
     const float dt0 = dt * (float)c->n;
     TRY(advect_prepare(c, {U0, V0}, U0, V0, dt0));
@@ -459,34 +526,31 @@ int dens_step(fluid_ctx* c, float dt, float diff, int iters)
     return op_advect(c, 0, X, X0, FLUID_U, FLUID_V, dt);
 }
 
-// One loop body of the reference's main.  The density's source term and its
-// halo are brought forward so that ONE exchange serves all three diffusions
-// (they are independent of each other; the arithmetic per cell is unchanged).
+// One loop body of the reference's main (FluidSequential.c:305-306).  The density's
+// source term and diffusion are brought forward next to the velocity's: the three
+// diffusions are independent of one another and of everything in between, so they
+// run as ONE batch (one exchange on slabs, three times the waves per launch); the
+// arithmetic per cell and the final contents of all six fields are unchanged.
 int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
 {
-    if (c->nranks > 1 && iters > 0) {
-        TRY(op_add_source(c, FLUID_U, FLUID_U_PREV, dt));
-        TRY(op_add_source(c, FLUID_V, FLUID_V_PREV, dt));
-        TRY(op_add_source(c, FLUID_DENS, FLUID_DENS_PREV, dt));
-        // right-hand sides and first guesses together (zeroed sources are valid everywhere and skipped)
-        const int h = std::min(iters, c->halo);
-        TRY(need(c, {FLUID_U, FLUID_V, FLUID_DENS, FLUID_U_PREV, FLUID_V_PREV, FLUID_DENS_PREV}, h));
-        float alpha, beta;
-        coefficients(c->n, dt, visc, &alpha, &beta);
-        TRY(op_diffuse(c, 1, FLUID_U_PREV, FLUID_U, alpha, beta, iters));
-        TRY(op_diffuse(c, 2, FLUID_V_PREV, FLUID_V, alpha, beta, iters));
-        TRY(project(c, FLUID_U_PREV, FLUID_V_PREV, FLUID_U, FLUID_V, iters));
-        TRY(advect_prepare(c, {FLUID_U_PREV, FLUID_V_PREV}, FLUID_U_PREV, FLUID_V_PREV, dt * (float)c->n));
-        TRY(op_advect(c, 1, FLUID_U, FLUID_U_PREV, FLUID_U_PREV, FLUID_V_PREV, dt));
-        TRY(op_advect(c, 2, FLUID_V, FLUID_V_PREV, FLUID_U_PREV, FLUID_V_PREV, dt));
-        TRY(project(c, FLUID_U, FLUID_V, FLUID_U_PREV, FLUID_V_PREV, iters));
-        coefficients(c->n, dt, diff, &alpha, &beta);
-        TRY(op_diffuse(c, 0, FLUID_DENS_PREV, FLUID_DENS, alpha, beta, iters));
-        TRY(advect_prepare(c, {FLUID_DENS_PREV}, FLUID_U, FLUID_V, dt * (float)c->n));
-        return op_advect(c, 0, FLUID_DENS, FLUID_DENS_PREV, FLUID_U, FLUID_V, dt);
-    }
-    TRY(vel_step(c, dt, visc, iters));
-    return dens_step(c, dt, diff, iters);
+    const int U = FLUID_U, V = FLUID_V, D = FLUID_DENS, U0 = FLUID_U_PREV, V0 = FLUID_V_PREV, D0 = FLUID_DENS_PREV;
+    TRY(op_add_source(c, U, U0, dt));
+    TRY(op_add_source(c, V, V0, dt));
+    TRY(op_add_source(c, D, D0, dt));
+    // right-hand sides and first guesses together (zeroed sources are valid everywhere and skipped)
+    TRY(need(c, {U, V, D, U0, V0, D0}, std::min(iters, c->halo)));
+    float av, bv, ad, bd;
+    coefficients(c->n, dt, visc, &av, &bv);
+    coefficients(c->n, dt, diff, &ad, &bd);
+    const Solve all[3] = {{1, U0, U, av, bv}, {2, V0, V, av, bv}, {0, D0, D, ad, bd}};
+    TRY(op_diffuse_batch(c, all, 3, iters));
+    TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
+    TRY(advect_prepare(c, {U0, V0}, U0, V0, dt * (float)c->n));
+    TRY(op_advect(c, 1, U, U0, U0, V0, dt));
+    TRY(op_advect(c, 2, V, V0, U0, V0, dt));
+    TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters));
+    TRY(advect_prepare(c, {D0}, U, V, dt * (float)c->n));
+    return op_advect(c, 0, D, D0, U, V, dt);
 }
 
 int zero_sources(fluid_ctx* c)
