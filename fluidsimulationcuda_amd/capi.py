@@ -15,7 +15,7 @@ U, V, DENS, U_PREV, V_PREV, DENS_PREV, TMP0, TMP1, TMP2 = range(9)
 NFIELDS = 9
 JACOBI_STREAM, JACOBI_LDS, JACOBI_NAIVE, JACOBI_TB = 0, 1, 2, 3
 PARAM_TB_MAX_SWEEPS, PARAM_TB_ROWS, PARAM_HALO, PARAM_TB_FAST_DIVISION, PARAM_TB_MIN_CELLS = 0, 1, 2, 3, 4
-XCHG_HALO, XCHG_GATHER, XCHG_MAX = 0, 1, 2
+XCHG_HALO, XCHG_GATHER, XCHG_MAX, XCHG_MAX_BEGIN, XCHG_MAX_END = 0, 1, 2, 3, 4
 FIELD_NAMES = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev", "tmp0", "tmp1", "tmp2")
 
 
@@ -61,6 +61,7 @@ SIGNATURES = {
     "fluid_synchronize": [_ctx],
     "fluid_owned_rows": [_ctx, C.POINTER(_i), C.POINTER(_i)],
     "fluid_field_ptr": [_ctx, _i, C.POINTER(C.c_void_p)],
+    "fluid_scalar_ptr": [_ctx, C.POINTER(C.c_void_p)],
     "fluid_upload": [_ctx, _i, _HOSTF],
     "fluid_download": [_ctx, _i, _HOSTF],
     "fluid_upload_rows": [_ctx, _i, _HOSTF, _i, _i],

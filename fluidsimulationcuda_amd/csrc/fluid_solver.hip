@@ -47,6 +47,7 @@ int fail(int code, const char* fmt, ...)
         if (rc_ != FLUID_OK) return rc_; \
     } while (0)
 
+constexpr size_t kControlBytes = 256;   // tail of the arena: reduction scalar (+0), division-proof counter (+8)
 constexpr int kMaxN = 1 << 20;   // index arithmetic is size_t; advect's clamp constant needs N < 2^23
 
 }  // namespace
@@ -61,6 +62,7 @@ struct fluid_ctx {
     float* f[FLUID_NFIELDS] = {};
     unsigned int* d_scalar = nullptr;     // device word for the reductions
     unsigned int* h_scalar = nullptr;     // pinned host mirror
+    hipEvent_t scalar_ready = nullptr;    // recorded behind the scalar's device-to-host copy
     int variant = fluid::JACOBI_TB;
     int tb_max_t = 8, tb_rows = 0, num_cu = 256;   // temporal blocking: sweeps/launch cap, rows/strip (0 = auto)
     long long tb_min_cells = 1500000;              // smaller slabs use single-sweep launches
@@ -406,14 +408,27 @@ int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int 
 // slab first learns the global bound (wavefront reduction + MAX exchange) and
 // makes sure that many rows of the advected field(s) are valid past its edges;
 // when the reach exceeds what a neighbour can supply it gathers whole fields.
-int advect_prepare(fluid_ctx* c, std::initializer_list<int> sources, int u, int v, float dt0)
+// The bound is a host decision, i.e. a pipeline drain: vmax_begin() only
+// enqueues (reduction kernel, device-side all-reduce, copy to pinned memory),
+// so the caller can put independent work behind it before advect_halo() waits.
+int vmax_begin(fluid_ctx* c, int u, int v)
 {
     if (c->nranks == 1) return FLUID_OK;
     HIP_TRY(hipMemsetAsync(c->d_scalar, 0, sizeof(unsigned), c->stream));
     fluid::launch_absmax2(c->stream, c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, c->d_scalar);
+    TRY(exchange(c, FLUID_XCHG_MAX_BEGIN, {}, 0));       // in-place MAX over ranks on the device scalar
+    HIP_TRY(hipMemcpyAsync(c->h_scalar, c->d_scalar, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->scalar_ready, c->stream));
+    return FLUID_OK;
+}
+
+int advect_halo(fluid_ctx* c, std::initializer_list<int> sources, float dt0)
+{
+    if (c->nranks == 1) return FLUID_OK;
+    HIP_TRY(hipEventSynchronize(c->scalar_ready));
     float vmax = 0.f;
-    TRY(reduce_to_host(c, &vmax));
-    TRY(exchange(c, FLUID_XCHG_MAX, {}, 0, &vmax));
+    std::memcpy(&vmax, c->h_scalar, sizeof vmax);
+    TRY(exchange(c, FLUID_XCHG_MAX_END, {}, 0, &vmax));  // transports that reduce on the host finish here
     const double reach = std::ceil((double)std::fabs(dt0) * (double)vmax) + 2.0;
     if (!(reach <= (double)exchange_cap(c))) {     // also catches NaN/inf
         TRY(exchange(c, FLUID_XCHG_GATHER, sources, 0));
@@ -421,6 +436,12 @@ int advect_prepare(fluid_ctx* c, std::initializer_list<int> sources, int u, int 
         return FLUID_OK;
     }
     return need(c, sources, (int)reach);
+}
+
+int advect_prepare(fluid_ctx* c, std::initializer_list<int> sources, int u, int v, float dt0)
+{
+    TRY(vmax_begin(c, u, v));
+    return advect_halo(c, sources, dt0);
 }
 
 int op_advect(fluid_ctx* c, int b, int d, int d0, int u, int v, float dt)
@@ -542,14 +563,31 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
     float av, bv, ad, bd;
     coefficients(c->n, dt, visc, &av, &bv);
     coefficients(c->n, dt, diff, &ad, &bd);
+    const float dt0 = dt * (float)c->n;
     const Solve all[3] = {{1, U0, U, av, bv}, {2, V0, V, av, bv}, {0, D0, D, ad, bd}};
-    TRY(op_diffuse_batch(c, all, 3, iters));
+    if (c->nranks == 1) {
+        TRY(op_diffuse_batch(c, all, 3, iters));
+        TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
+        TRY(op_advect(c, 1, U, U0, U0, V0, dt));
+        TRY(op_advect(c, 2, V, V0, U0, V0, dt));
+        TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters));
+        return op_advect(c, 0, D, D0, U, V, dt);
+    }
+    // Slabs: each advect needs the global max |velocity| on the host -- a pipeline drain.  The
+    // density diffusion depends on nothing in between, so its sweeps are enqueued behind each
+    // reduction (in two parts) and the GPU stays busy while the host waits and talks to its peers.
+    const int part1 = std::min(iters, ((iters * 3 / 5) + 7) / 8 * 8), part2 = iters - part1;
+    TRY(op_diffuse_batch(c, all, 2, iters));
     TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
-    TRY(advect_prepare(c, {U0, V0}, U0, V0, dt * (float)c->n));
+    TRY(vmax_begin(c, U0, V0));
+    TRY(op_diffuse_batch(c, all + 2, 1, part1));
+    TRY(advect_halo(c, {U0, V0}, dt0));
     TRY(op_advect(c, 1, U, U0, U0, V0, dt));
     TRY(op_advect(c, 2, V, V0, U0, V0, dt));
     TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters));
-    TRY(advect_prepare(c, {D0}, U, V, dt * (float)c->n));
+    TRY(vmax_begin(c, U, V));
+    TRY(op_diffuse_batch(c, all + 2, 1, part2));
+    TRY(advect_halo(c, {D0}, dt0));
     return op_advect(c, 0, D, D0, U, V, dt);
 }
 
@@ -611,7 +649,7 @@ size_t fluid_arena_bytes(int N)
 {
     size_t ff = 0;
     if (fluid_layout(N, nullptr, nullptr, &ff) != FLUID_OK) return 0;
-    return ff * FLUID_NFIELDS * sizeof(float);
+    return ff * FLUID_NFIELDS * sizeof(float) + kControlBytes;
 }
 
 int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
@@ -644,7 +682,7 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
     // 1024-row slab; shallower on short slabs
     const int want = cfg->halo > 0 ? cfg->halo : std::max(4, std::min(42, base / 8));
     c->halo = P > 1 ? std::max(1, std::min(want, base - 1)) : 1;
-    const size_t bytes = c->field_floats * FLUID_NFIELDS * sizeof(float);
+    const size_t bytes = c->field_floats * FLUID_NFIELDS * sizeof(float) + kControlBytes;
     int rc = FLUID_OK;
     auto bail = [&](int code) { fluid_destroy(c); return code; };
     if (cfg->arena) {
@@ -676,8 +714,9 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
             c->num_cu = cus;
     }
     if (!hip_ok(hipMemsetAsync(c->arena, 0, bytes, c->stream), "hipMemsetAsync(arena)")) return bail(rc);
-    if (!hip_ok(hipMalloc((void**)&c->d_scalar, 256), "hipMalloc(scalar)")) return bail(rc);
+    c->d_scalar = reinterpret_cast<unsigned int*>(c->arena + c->field_floats * FLUID_NFIELDS);   // RCCL-addressable
     if (!hip_ok(hipHostMalloc((void**)&c->h_scalar, 256, hipHostMallocDefault), "hipHostMalloc")) return bail(rc);
+    if (!hip_ok(hipEventCreateWithFlags(&c->scalar_ready, hipEventDisableTiming), "hipEventCreate")) return bail(rc);
     if (!hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return bail(rc);
     *out = c;
     return FLUID_OK;
@@ -701,8 +740,8 @@ int fluid_destroy(fluid_ctx* c)
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
     }
-    if (c->d_scalar) (void)hipFree(c->d_scalar);
     if (c->h_scalar) (void)hipHostFree(c->h_scalar);
+    if (c->scalar_ready) (void)hipEventDestroy(c->scalar_ready);
     if (c->own_arena && c->arena) (void)hipFree(c->arena);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (g_cached == c) g_cached = nullptr;
@@ -731,6 +770,14 @@ int fluid_field_ptr(fluid_ctx* c, int field, void** dev_ptr)
     TRY(check_fields(c, {field}));
     if (!dev_ptr) return fail(FLUID_E_INVALID, "null pointer");
     *dev_ptr = c->f[field];
+    return FLUID_OK;
+}
+
+int fluid_scalar_ptr(fluid_ctx* c, void** dev_ptr)
+{
+    TRY(check_ctx(c));
+    if (!dev_ptr) return fail(FLUID_E_INVALID, "null pointer");
+    *dev_ptr = c->d_scalar;
     return FLUID_OK;
 }
 

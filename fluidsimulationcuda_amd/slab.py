@@ -44,6 +44,8 @@ class TorchExchange:
         self.stream = stream        # torch.cuda.Stream the solver's kernels run on (None: CPU tensors)
         self.lo, self.hi = slab_rows(n, rank, nranks)
         self.calls = {capi.XCHG_HALO: 0, capi.XCHG_GATHER: 0, capi.XCHG_MAX: 0}
+        self.scalar = None          # 1-element float32 view of the solver's device reduction scalar
+        self._reduced_on_device = False
         # RCCL moves device memory directly.  gloo cannot, so device rows are
         # staged through host buffers: used only to rehearse the multi-process
         # path on a box with fewer GPUs than ranks (tests, bench --backend gloo).
@@ -61,6 +63,17 @@ class TorchExchange:
         return self._dispatch(kind, ids, depth, scalar)
 
     def _dispatch(self, kind, ids, depth, scalar):
+        if kind == capi.XCHG_MAX_BEGIN:
+            self.calls[capi.XCHG_MAX] += 1
+            if not self.staged and self.scalar is not None:
+                # non-negative floats: MAX on the device word, in place, on the solver's stream
+                dist.all_reduce(self.scalar, op=dist.ReduceOp.MAX, group=self.group)
+                self._reduced_on_device = True
+            else:
+                self._reduced_on_device = False
+            return None
+        if kind == capi.XCHG_MAX_END:
+            return scalar if self._reduced_on_device else self.maximum(scalar)
         self.calls[kind] += 1
         if kind == capi.XCHG_HALO:
             return self.halo(ids, depth)
@@ -161,6 +174,8 @@ class SlabSolver(FluidSolver):
         self.exchange = None
         if nranks > 1:
             self.exchange = TorchExchange(self.field_tensor, n, rank, nranks, group, stream=self.torch_stream)
+            off = (self.scalar_ptr() - self.arena.data_ptr()) // 4
+            self.exchange.scalar = self.arena[off:off + 1]
             self.set_exchange(self.exchange)
 
     def field_tensor(self, fid):

@@ -96,6 +96,11 @@ class FluidSolver:
         capi.check(capi.lib().fluid_field_ptr(self._h, _fid(field), C.byref(p)))
         return p.value
 
+    def scalar_ptr(self):
+        p = C.c_void_p()
+        capi.check(capi.lib().fluid_scalar_ptr(self._h, C.byref(p)))
+        return p.value
+
     # -- the reference's operators (same names / argument order)
     def set_bnd(self, b, x):
         capi.check(capi.lib().fluid_op_set_bnd(self._h, b, _fid(x)))
@@ -177,7 +182,7 @@ class FluidSolver:
         def tramp(_user, kind, fields, nfields, depth, scalar):
             try:
                 ids = [fields[k] for k in range(nfields)]
-                if kind == capi.XCHG_MAX:
+                if kind in (capi.XCHG_MAX, capi.XCHG_MAX_END):
                     scalar[0] = float(fn(kind, ids, depth, float(scalar[0])))
                 else:
                     fn(kind, ids, depth, None)

@@ -114,6 +114,9 @@ int fluid_owned_rows(fluid_ctx *ctx, int *row_lo, int *row_hi);
  * field keeps its id but may trade buffers with TMP0 inside a solve, so the
  * exchange callback must ask every time. */
 int fluid_field_ptr(fluid_ctx *ctx, int field, void **dev_ptr);
+/* Device address of the 4-byte reduction scalar (a non-negative float) that
+ * FLUID_XCHG_MAX_BEGIN reduces in place; it lives in the last 256 bytes of the arena. */
+int fluid_scalar_ptr(fluid_ctx *ctx, void **dev_ptr);
 
 /* Host <-> device copies of a whole field, or of rows [row_lo,row_hi) of it
  * (host pointer is always to the full (N+2)^2 array). Synchronous. */
@@ -184,9 +187,16 @@ int fluid_op_diffuse_tol(fluid_ctx *ctx, int b, int x, int x0, float alpha, floa
  *                      the rows just outside the owned range.
  *   FLUID_XCHG_GATHER: all-gather the owned rows (end slabs: plus the ghost
  *                      row) of each listed field, so every rank holds the full field.
- *   FLUID_XCHG_MAX   : *scalar = max over ranks of *scalar.
+ *   FLUID_XCHG_MAX   : *scalar = max over ranks of *scalar (host value, synchronous).
+ *   FLUID_XCHG_MAX_BEGIN / _END: the same reduction split so the solver can keep the GPU busy
+ *                      while it is in flight.  BEGIN (scalar == NULL): enqueue, on the context's
+ *                      stream, an in-place MAX over ranks of the device scalar (fluid_scalar_ptr);
+ *                      the solver then copies it to the host asynchronously.  END: *scalar holds
+ *                      that host copy; a transport that cannot reduce on the device leaves BEGIN
+ *                      empty and replaces *scalar by the max over ranks here.
  * Return 0 on success. */
-enum { FLUID_XCHG_HALO = 0, FLUID_XCHG_GATHER = 1, FLUID_XCHG_MAX = 2 };
+enum { FLUID_XCHG_HALO = 0, FLUID_XCHG_GATHER = 1, FLUID_XCHG_MAX = 2, FLUID_XCHG_MAX_BEGIN = 3,
+       FLUID_XCHG_MAX_END = 4 };
 typedef int (*fluid_exchange_fn)(void *user, int kind, const int *fields, int nfields,
                                  int depth, float *scalar);
 int fluid_set_exchange(fluid_ctx *ctx, fluid_exchange_fn fn, void *user);

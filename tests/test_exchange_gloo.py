@@ -59,6 +59,9 @@ def _worker(rank, world, port, n, q):
         ok &= bool((fields[1] == make(1)).all())            # unlisted fields untouched
         got = ex(capi.XCHG_MAX, [], 0, float(rank * 2 + 1))
         ok &= got == float((world - 1) * 2 + 1)
+        # split form: CPU tensors cannot be reduced "on the device", so END does the work
+        ok &= ex(capi.XCHG_MAX_BEGIN, [], 0, None) is None
+        ok &= ex(capi.XCHG_MAX_END, [], 0, float(10 - rank)) == 10.0
         ex(capi.XCHG_GATHER, [2], 0, None)
         ok &= bool((fields[2][:, 5] == torch.tensor([2000.0 + r for r in range(w)])).all())
         try:
@@ -83,7 +86,7 @@ def test_torch_exchange_over_gloo(world, n):
     assert all(p.exitcode == 0 for p in ps)
     for rank, ok, calls in res:
         assert ok, "rank %d saw wrong rows" % rank
-        assert calls[0] == 2 and calls[1] == 1 and calls[2] == 1
+        assert calls[0] == 2 and calls[1] == 1 and calls[2] == 2
 
 
 def test_slab_rows_partition():
