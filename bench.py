@@ -27,7 +27,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 KERNELS = ["stream", "lds", "naive", "tb"]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
-BYTES_PER_CELL_SWEEP = 12      # read x + read x0 + write x_new, fp32
+BYTES_PER_CELL_SWEEP = 12      # read x + read x0 + write x_new, fp32 (6 with fp16 storage)
 BYTES_PER_CELL_STEP = 2548     # SURVEY.md 8(d), 40 sweeps/solve
 
 
@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scaling-base", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+                    help="field storage: f32 (reference arithmetic, the measured configuration) or f16 "
+                         "(BASELINE config 4: fp16 fields, fp32 arithmetic)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured path) or gloo (host-staged rehearsal "
                                                       "of the multi-process path when ranks outnumber GPUs)")
     ap.add_argument("--check", action="store_true", help="multi-GPU: also verify bit equality with a 1-context run (small grids)")
@@ -167,7 +170,8 @@ def main():
 
     def run(n_, steps, warmup):
         fields = initialize_parameters(n_, seed=a.seed)     # same seed on every rank
-        s = SlabSolver(n_, rank=rank, nranks=world, halo=a.halo, jacobi=a.variant)
+        s = SlabSolver(n_, rank=rank, nranks=world, halo=a.halo, jacobi=a.variant,
+                       storage=1 if a.dtype == "f16" else 0)
         if a.tb_sweeps:
             s.set_param(0, a.tb_sweeps)
         if a.tb_rows:
@@ -202,7 +206,8 @@ def main():
     ms_step = elapsed * 1e3 / a.steps
     t_sweep = jac_ms * 1e-3 / max(sweeps, 1)
     mcells = cells / t_sweep / 1e6
-    achieved = BYTES_PER_CELL_SWEEP * cells / t_sweep / 1e9
+    bpc = BYTES_PER_CELL_SWEEP // (2 if a.dtype == "f16" else 1)
+    achieved = bpc * cells / t_sweep / 1e9
     fused = 1
     if a.variant == 3:
         fused = a.tb_sweeps or 8
@@ -213,7 +218,8 @@ def main():
     line = {
         "metric": "Mcells/s per Jacobi iter", "value": mcells, "unit": "Mcells/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if a.dtype == "f32" else "f16 storage, f32 arithmetic",
         "data": "synthetic (initializeParameters recipe, PCG64 seed %d)" % a.seed,
         "config": {"workload": "%dx%d grid, full vel_step+dens_step, %d Jacobi sweeps/solve (200/step), fp32"
                                % (grid, grid, a.iters),
@@ -222,7 +228,7 @@ def main():
                        world, "RCCL" if a.backend == "nccl" else a.backend + " (host-staged rehearsal)")},
         "ms_per_sim_step": ms_step,
         "us_per_jacobi_sweep": t_sweep * 1e6,
-        "step_algorithmic_GBps": BYTES_PER_CELL_STEP * cells / (ms_step * 1e-3) / 1e9,
+        "step_algorithmic_GBps": BYTES_PER_CELL_STEP // (2 if a.dtype == "f16" else 1) * cells / (ms_step * 1e-3) / 1e9,
         "roofline": {"bound": "hbm", "kernel": kernel_name,
                      "achieved": achieved * (1.0 / world), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / world / HBM_PEAK_GBS, "traffic": None,

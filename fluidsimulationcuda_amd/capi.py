@@ -14,6 +14,7 @@ OK, E_INVALID, E_NOMEM, E_HIP, E_COMM = 0, 1, 2, 3, 4
 U, V, DENS, U_PREV, V_PREV, DENS_PREV, TMP0, TMP1, TMP2 = range(9)
 NFIELDS = 9
 JACOBI_STREAM, JACOBI_LDS, JACOBI_NAIVE, JACOBI_TB = 0, 1, 2, 3
+STORAGE_F32, STORAGE_F16 = 0, 1
 PARAM_TB_MAX_SWEEPS, PARAM_TB_ROWS, PARAM_HALO, PARAM_TB_FAST_DIVISION, PARAM_TB_MIN_CELLS = 0, 1, 2, 3, 4
 XCHG_HALO, XCHG_GATHER, XCHG_MAX, XCHG_MAX_BEGIN, XCHG_MAX_END = 0, 1, 2, 3, 4
 FIELD_NAMES = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev", "tmp0", "tmp1", "tmp2")
@@ -28,7 +29,7 @@ class FluidError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("n", C.c_int), ("rank", C.c_int), ("nranks", C.c_int), ("halo", C.c_int),
                 ("jacobi_variant", C.c_int), ("stream", C.c_void_p), ("arena", C.c_void_p),
-                ("arena_bytes", C.c_size_t)]
+                ("arena_bytes", C.c_size_t), ("storage", C.c_int)]
 
 
 TIME_SOURCE, TIME_DIFFUSION, TIME_DIVERGENCE, TIME_PROJECTION, TIME_ADVECTION = range(5)
@@ -87,7 +88,8 @@ SIGNATURES = {
     "fluid_set_exchange": [_ctx, EXCHANGE_FN, C.c_void_p],
 }
 # symbols with a non-status return type
-OTHER_SYMBOLS = {"fluid_last_error": (C.c_char_p, []), "fluid_arena_bytes": (C.c_size_t, [_i])}
+OTHER_SYMBOLS = {"fluid_last_error": (C.c_char_p, []), "fluid_arena_bytes": (C.c_size_t, [_i]),
+                 "fluid_arena_bytes_ex": (C.c_size_t, [_i, _i])}
 
 _lib = None
 

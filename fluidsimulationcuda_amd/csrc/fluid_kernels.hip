@@ -30,6 +30,34 @@ namespace fluid {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float flip_if(bool c, float v) { return c ? -v : v; }
 
+// Field storage type S: float (the reference's arithmetic, bit for bit) or
+// _Float16 (BASELINE config 4: fp16 fields, every operation still in fp32 on the
+// widened values, one round-to-nearest when a kernel stores).
+// With fp16 storage hipcc likes to fold the widening / narrowing conversions into
+// mixed-precision instructions (observed: fmul + fptrunc -> v_fma_mixlo_f16 x, y, 0),
+// which rounds the exact product straight to fp16 and adds a +0 that flips -0
+// results: neither is "the fp32 operation, then one rounding on store".  An empty
+// asm on the value (no instruction) keeps the conversions separate.
+__device__ __forceinline__ float keep_f32(float v) { asm("" : "+v"(v)); return v; }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const half_t* p) { return keep_f32((float)*p); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(half_t* p, float v) { *p = (half_t)keep_f32(v); }
+typedef half_t half4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const half_t* p)
+{
+    const half4_t h = *reinterpret_cast<const half4_t*>(p);
+    return make_float4(keep_f32((float)h.x), keep_f32((float)h.y), keep_f32((float)h.z), keep_f32((float)h.w));
+}
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(half_t* p, const float4& v)
+{
+    half4_t h;
+    h.x = (half_t)keep_f32(v.x); h.y = (half_t)keep_f32(v.y); h.z = (half_t)keep_f32(v.z); h.w = (half_t)keep_f32(v.w);
+    *reinterpret_cast<half4_t*>(p) = h;
+}
+
 // value of lane-1 / lane+1 across the whole 64-wide wave (DPP wave shifts; one
 // VALU op each, no LDS).  Lane 0 / 63 receive `edge`.
 __device__ __forceinline__ float from_lane_below(float v, float edge)
@@ -61,8 +89,8 @@ __device__ __forceinline__ float lane_above0(float v)
 // b==1, across a horizontal wall -val when b==2, else a copy; a corner is
 // 0.5f*(horizontal neighbour + vertical neighbour), both of which are ghosts of
 // the same corner-most interior cell.  Handles n==1 (a cell on several walls).
-__device__ __forceinline__ void emit_ghosts(float* __restrict__ f, size_t pitch, int n, int b,
-                                                 int j, int i, float val)
+template <typename S>
+__device__ __forceinline__ void emit_ghosts(S* __restrict__ f, size_t pitch, int n, int b, int j, int i, float val)
 {
     const bool nx = (b == 1), ny = (b == 2);
     const bool left = (j == 1), right = (j == n), top = (i == 1), bot = (i == n);
@@ -70,17 +98,17 @@ __device__ __forceinline__ void emit_ghosts(float* __restrict__ f, size_t pitch,
     const float gx = flip_if(nx, val);
     const float gy = flip_if(ny, val);
     const float corner = 0.5f * (gy + gx);   // 0.5f*(x[horizontal nbr] + x[vertical nbr])
-    float* r0 = f + XOFF;
-    float* ri = f + (size_t)i * pitch + XOFF;
-    float* rn = f + (size_t)(n + 1) * pitch + XOFF;
-    if (left) ri[0] = gx;
-    if (right) ri[n + 1] = gx;
-    if (top) r0[j] = gy;
-    if (bot) rn[j] = gy;
-    if (top & left) r0[0] = corner;
-    if (top & right) r0[n + 1] = corner;
-    if (bot & left) rn[0] = corner;
-    if (bot & right) rn[n + 1] = corner;
+    S* r0 = f + XOFF;
+    S* ri = f + (size_t)i * pitch + XOFF;
+    S* rn = f + (size_t)(n + 1) * pitch + XOFF;
+    if (left) st1(ri, gx);
+    if (right) st1(ri + n + 1, gx);
+    if (top) st1(r0 + j, gy);
+    if (bot) st1(rn + j, gy);
+    if (top & left) st1(r0, corner);
+    if (top & right) st1(r0 + n + 1, corner);
+    if (bot & left) st1(rn, corner);
+    if (bot & right) st1(rn + n + 1, corner);
 }
 
 // ---------------------------------------------------------------------------
@@ -88,32 +116,33 @@ __device__ __forceinline__ void emit_ghosts(float* __restrict__ f, size_t pitch,
 // the fused form).  One thread per edge index k in 1..n; thread k==1 / k==n
 // also writes the corners from the values it just produced.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_set_bnd(float* __restrict__ f, int pitch, int n, int b)
+template <typename S>
+__global__ __launch_bounds__(256) void k_set_bnd(S* __restrict__ f, int pitch, int n, int b)
 {
     const int k = 1 + blockIdx.x * 256 + threadIdx.x;
     if (k > n) return;
     const size_t P = (size_t)pitch;
     const bool nx = (b == 1), ny = (b == 2);
-    float* r0 = f + XOFF;
-    float* rk = f + (size_t)k * P + XOFF;
-    float* r1 = f + P + XOFF;
-    float* rN = f + (size_t)n * P + XOFF;
-    float* rn = f + (size_t)(n + 1) * P + XOFF;
-    const float gl = flip_if(nx, rk[1]);      // x[0,k]
-    const float gr = flip_if(nx, rk[n]);      // x[n+1,k]
-    const float gt = flip_if(ny, r1[k]);      // x[k,0]
-    const float gb = flip_if(ny, rN[k]);      // x[k,n+1]
-    rk[0] = gl;
-    rk[n + 1] = gr;
-    r0[k] = gt;
-    rn[k] = gb;
+    S* r0 = f + XOFF;
+    S* rk = f + (size_t)k * P + XOFF;
+    S* r1 = f + P + XOFF;
+    S* rN = f + (size_t)n * P + XOFF;
+    S* rn = f + (size_t)(n + 1) * P + XOFF;
+    const float gl = flip_if(nx, ld1(rk + 1));      // x[0,k]
+    const float gr = flip_if(nx, ld1(rk + n));      // x[n+1,k]
+    const float gt = flip_if(ny, ld1(r1 + k));      // x[k,0]
+    const float gb = flip_if(ny, ld1(rN + k));      // x[k,n+1]
+    st1(rk, gl);
+    st1(rk + n + 1, gr);
+    st1(r0 + k, gt);
+    st1(rn + k, gb);
     if (k == 1) {
-        r0[0] = 0.5f * (gt + gl);                            // x[1,0] + x[0,1]
-        rn[0] = 0.5f * (gb + flip_if(nx, rN[1]));            // x[1,n+1] + x[0,n]
+        st1(r0, 0.5f * (gt + gl));                                  // x[1,0] + x[0,1]
+        st1(rn, 0.5f * (gb + flip_if(nx, ld1(rN + 1))));            // x[1,n+1] + x[0,n]
     }
     if (k == n) {
-        r0[n + 1] = 0.5f * (gt + flip_if(nx, r1[n]));        // x[n,0] + x[n+1,1]
-        rn[n + 1] = 0.5f * (gb + gr);                        // x[n,n+1] + x[n+1,n]
+        st1(r0 + n + 1, 0.5f * (gt + flip_if(nx, ld1(r1 + n))));    // x[n,0] + x[n+1,1]
+        st1(rn + n + 1, 0.5f * (gb + gr));                          // x[n,n+1] + x[n+1,n]
     }
 }
 
@@ -122,21 +151,22 @@ __global__ __launch_bounds__(256) void k_set_bnd(float* __restrict__ f, int pitc
 // included (FluidSequential.c:78-82).  Streams whole padded rows as float4
 // (pads are 0 and stay 0).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_add_source(float* __restrict__ x, const float* __restrict__ s,
-                                                    int pitch, int row_lo, int row_hi, float dt)
+template <typename S>
+__global__ __launch_bounds__(256) void k_add_source(S* __restrict__ x, const S* __restrict__ s, int pitch, int row_lo,
+                                                    int row_hi, float dt)
 {
     const int nvec = pitch >> 2;
     const size_t total = (size_t)(row_hi - row_lo) * nvec;
-    float4* xv = reinterpret_cast<float4*>(x + (size_t)row_lo * pitch);
-    const float4* sv = reinterpret_cast<const float4*>(s + (size_t)row_lo * pitch);
+    S* xv = x + (size_t)row_lo * pitch;
+    const S* sv = s + (size_t)row_lo * pitch;
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
-        float4 a = xv[t];
-        const float4 c = sv[t];
+        float4 a = ld4(xv + 4 * t);
+        const float4 c = ld4(sv + 4 * t);
         a.x = a.x + dt * c.x;
         a.y = a.y + dt * c.y;
         a.z = a.z + dt * c.z;
         a.w = a.w + dt * c.w;
-        xv[t] = a;
+        st4(xv + 4 * t, a);
     }
 }
 
@@ -148,20 +178,21 @@ __global__ __launch_bounds__(256) void k_add_source(float* __restrict__ x, const
 // ---------------------------------------------------------------------------
 
 // (i) naive-global: one thread per cell, five global loads.
-__global__ __launch_bounds__(256) void k_jacobi_naive(const float* __restrict__ x, const float* __restrict__ x0,
-                                                      float* __restrict__ out, int pitch, int n, int row_lo,
+template <typename S>
+__global__ __launch_bounds__(256) void k_jacobi_naive(const S* __restrict__ x, const S* __restrict__ x0,
+                                                      S* __restrict__ out, int pitch, int n, int row_lo,
                                                       int row_hi, float alpha, float beta, int b)
 {
     const int j = 1 + blockIdx.x * 64 + (threadIdx.x & 63);
     const int i = row_lo + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (j > n || i >= row_hi) return;
     const size_t P = (size_t)pitch;
-    const float* c = x + (size_t)i * P + XOFF + j;
-    float nb = c[-1] + c[1];
-    nb = nb + c[-(ptrdiff_t)P];
-    nb = nb + c[P];
-    const float val = (x0[(size_t)i * P + XOFF + j] + alpha * nb) / beta;
-    out[(size_t)i * P + XOFF + j] = val;
+    const S* c = x + (size_t)i * P + XOFF + j;
+    float nb = ld1(c - 1) + ld1(c + 1);
+    nb = nb + ld1(c - (ptrdiff_t)P);
+    nb = nb + ld1(c + P);
+    const float val = (ld1(x0 + (size_t)i * P + XOFF + j) + alpha * nb) / beta;
+    st1(out + (size_t)i * P + XOFF + j, val);
     emit_ghosts(out, P, n, b, j, i, val);
 }
 
@@ -169,8 +200,9 @@ __global__ __launch_bounds__(256) void k_jacobi_naive(const float* __restrict__ 
 // (TX=64, TY=16, 256 threads, each thread 4 rows of one column).  Tile corners
 // are not needed by a 5-point stencil and are not loaded.
 constexpr int LT_X = 64, LT_Y = 16;
-__global__ __launch_bounds__(256) void k_jacobi_lds(const float* __restrict__ x, const float* __restrict__ x0,
-                                                    float* __restrict__ out, int pitch, int n, int row_lo,
+template <typename S>
+__global__ __launch_bounds__(256) void k_jacobi_lds(const S* __restrict__ x, const S* __restrict__ x0,
+                                                    S* __restrict__ out, int pitch, int n, int row_lo,
                                                     int row_hi, float alpha, float beta, int b)
 {
     __shared__ float tile[LT_Y + 2][LT_X + 2 + 1];
@@ -182,13 +214,13 @@ __global__ __launch_bounds__(256) void k_jacobi_lds(const float* __restrict__ x,
     const int cols = min(LT_X, n - j0 + 1);
     // body + top/bottom halo rows: rows i0-1 .. i0+rows, 64 columns each
     for (int r = ty; r < rows + 2; r += 4)
-        if (tx < cols) tile[r][tx + 1] = x[(size_t)(i0 - 1 + r) * P + XOFF + j];
+        if (tx < cols) tile[r][tx + 1] = ld1(x + (size_t)(i0 - 1 + r) * P + XOFF + j);
     // left/right halo columns
     if (threadIdx.x < 2 * LT_Y) {
         const int r = threadIdx.x >> 1, side = threadIdx.x & 1;
         if (r < rows) {
             const int jj = side ? j0 + cols : j0 - 1;
-            tile[r + 1][side ? cols + 1 : 0] = x[(size_t)(i0 + r) * P + XOFF + jj];
+            tile[r + 1][side ? cols + 1 : 0] = ld1(x + (size_t)(i0 + r) * P + XOFF + jj);
         }
     }
     __syncthreads();
@@ -201,8 +233,8 @@ __global__ __launch_bounds__(256) void k_jacobi_lds(const float* __restrict__ x,
         float nb = tile[r + 1][tx] + tile[r + 1][tx + 2];
         nb = nb + tile[r][tx + 1];
         nb = nb + tile[r + 2][tx + 1];
-        const float val = (x0[(size_t)i * P + XOFF + j] + alpha * nb) / beta;
-        out[(size_t)i * P + XOFF + j] = val;
+        const float val = (ld1(x0 + (size_t)i * P + XOFF + j) + alpha * nb) / beta;
+        st1(out + (size_t)i * P + XOFF + j, val);
         emit_ghosts(out, P, n, b, j, i, val);
     }
 }
@@ -212,9 +244,9 @@ __global__ __launch_bounds__(256) void k_jacobi_lds(const float* __restrict__ x,
 // (+2 halo rows per RB); left/right neighbours come from the adjacent lanes by
 // DPP wave shift, and only the wave's two edge lanes issue an extra dword load.
 // 16 bytes per lane, 1 KiB per wave-instruction, 256-byte aligned.
-template <int RB>
-__global__ __launch_bounds__(256) void k_jacobi_stream(const float* __restrict__ x, const float* __restrict__ x0,
-                                                       float* __restrict__ out, int pitch, int n, int row_lo,
+template <int RB, typename S>
+__global__ __launch_bounds__(256) void k_jacobi_stream(const S* __restrict__ x, const S* __restrict__ x0,
+                                                       S* __restrict__ out, int pitch, int n, int row_lo,
                                                        int row_hi, float alpha, float beta, int b)
 {
     const int lane = threadIdx.x & 63;
@@ -226,20 +258,20 @@ __global__ __launch_bounds__(256) void k_jacobi_stream(const float* __restrict__
     const int v = active ? vec : nvec - 1;              // clamp: inactive lanes load valid memory
     const int j = 1 + 4 * v;                            // first column of this lane
     const size_t P = (size_t)pitch;
-    const float* xc = x + XOFF + j;
-    const float* rc = x0 + XOFF + j;
-    float* oc = out + XOFF + j;
+    const S* xc = x + XOFF + j;
+    const S* rc = x0 + XOFF + j;
+    S* oc = out + XOFF + j;
     const bool edge_lo = (lane == 0), edge_hi = (lane == 63) | (vec >= nvec - 1);
     const bool nx = (b == 1), ny = (b == 2);
 
-    float4 up = *reinterpret_cast<const float4*>(xc + (size_t)(i0 - 1) * P);
-    float4 me = *reinterpret_cast<const float4*>(xc + (size_t)i0 * P);
+    float4 up = ld4(xc + (size_t)(i0 - 1) * P);
+    float4 me = ld4(xc + (size_t)i0 * P);
     for (int i = i0; i < i1; ++i) {
-        const float4 dn = *reinterpret_cast<const float4*>(xc + (size_t)(i + 1) * P);
-        const float4 r = *reinterpret_cast<const float4*>(rc + (size_t)i * P);
+        const float4 dn = ld4(xc + (size_t)(i + 1) * P);
+        const float4 r = ld4(rc + (size_t)i * P);
         float le = 0.f, re = 0.f;
-        if (edge_lo) le = xc[(size_t)i * P - 1];
-        if (edge_hi) re = xc[(size_t)i * P + 4];
+        if (edge_lo) le = ld1(xc + (size_t)i * P - 1);
+        if (edge_hi) re = ld1(xc + (size_t)i * P + 4);
         float L = from_lane_below(me.w, le);
         float R = from_lane_above(me.x, re);
         if (edge_lo) L = le;
@@ -251,19 +283,19 @@ __global__ __launch_bounds__(256) void k_jacobi_stream(const float* __restrict__
         nb = me.y + me.w;  nb = nb + up.z; nb = nb + dn.z; o.z = (r.z + alpha * nb) / beta;
         nb = me.z + R;     nb = nb + up.w; nb = nb + dn.w; o.w = (r.w + alpha * nb) / beta;
         if (active) {
-            float* orow = oc + (size_t)i * P;
+            S* orow = oc + (size_t)i * P;
             const int last = n - j;            // component index of column n (>=0)
             if (last >= 3) {
-                *reinterpret_cast<float4*>(orow) = o;
+                st4(orow, o);
             } else {                           // ragged right end: columns j..n only
-                orow[0] = o.x;
-                if (last >= 1) orow[1] = o.y;
-                if (last >= 2) orow[2] = o.z;
+                st1(orow, o.x);
+                if (last >= 1) st1(orow + 1, o.y);
+                if (last >= 2) st1(orow + 2, o.z);
             }
             // ---- fused set_bnd (selects only: no runtime-indexed arrays) ----
             const float vn = last == 0 ? o.x : last == 1 ? o.y : last == 2 ? o.z : o.w;  // column n
-            if (j == 1) orow[-1] = flip_if(nx, o.x);                       // x[0,i]
-            if (last <= 3) orow[last + 1] = flip_if(nx, vn);               // x[n+1,i]
+            if (j == 1) st1(orow - 1, flip_if(nx, o.x));                   // x[0,i]
+            if (last <= 3) st1(orow + last + 1, flip_if(nx, vn));          // x[n+1,i]
             if (i == 1 || i == n) {
                 float4 g4;
                 g4.x = flip_if(ny, o.x); g4.y = flip_if(ny, o.y);
@@ -273,16 +305,16 @@ __global__ __launch_bounds__(256) void k_jacobi_stream(const float* __restrict__
 #pragma unroll
                 for (int side = 0; side < 2; ++side) {
                     if (side == 0 ? i != 1 : i != n) continue;
-                    float* g = oc + (side == 0 ? (size_t)0 : (size_t)(n + 1) * P);
+                    S* g = oc + (side == 0 ? (size_t)0 : (size_t)(n + 1) * P);
                     if (last >= 3) {
-                        *reinterpret_cast<float4*>(g) = g4;
+                        st4(g, g4);
                     } else {
-                        g[0] = g4.x;
-                        if (last >= 1) g[1] = g4.y;
-                        if (last >= 2) g[2] = g4.z;
+                        st1(g, g4.x);
+                        if (last >= 1) st1(g + 1, g4.y);
+                        if (last >= 2) st1(g + 2, g4.z);
                     }
-                    if (j == 1) g[-1] = cl;
-                    if (last <= 3) g[last + 1] = cr;
+                    if (j == 1) st1(g - 1, cl);
+                    if (last <= 3) st1(g + last + 1, cr);
                 }
             }
         }
@@ -329,10 +361,11 @@ __global__ __launch_bounds__(256) void k_jacobi_stream(const float* __restrict__
 //   on a denormal midpoint, possible for a few even-integer-like beta -- is why
 //   the solver proves each beta on the device before using this mode:
 //   k_validate_div compares it with a/beta for all 2^32 inputs (about 6 op times).
+template <typename S>
 struct TbArgs {
-    const float* xc;      // x   + column offset of this lane
-    const float* rc;      // x0  + column offset
-    float* oc;            // out + column offset
+    const S* xc;          // x   + column offset of this lane
+    const S* rc;          // x0  + column offset
+    S* oc;                // out + column offset
     size_t P;
     int n, q_lo, q_hi, t_ld, cg, last;
     float alpha, beta;
@@ -386,7 +419,8 @@ __global__ __launch_bounds__(256) void k_validate_div(float beta, float arg, dou
 
 // ghost columns of one freshly computed row (set_bnd, FluidSequential.c:65-66);
 // v1 / vn return column 1 / column n of the row (for the corners).
-__device__ __forceinline__ void tb_fix_columns(float4& G, const TbArgs& a, float& v1, float& vn)
+template <typename S>
+__device__ __forceinline__ void tb_fix_columns(float4& G, const TbArgs<S>& a, float& v1, float& vn)
 {
     if (a.left_edge) {
         v1 = lane_above0(G.x);
@@ -403,16 +437,16 @@ __device__ __forceinline__ void tb_fix_columns(float4& G, const TbArgs& a, float
 }
 
 // final stage: store row q, its ghost columns, and ghost rows / corners
-template <bool EDGE>
-__device__ __forceinline__ void tb_store(const float4& G, int q, const TbArgs& a, float v1, float vn)
+template <bool EDGE, typename S>
+__device__ __forceinline__ void tb_store(const float4& G, int q, const TbArgs<S>& a, float v1, float vn)
 {
     const bool top = (q == 1), bot = (q == a.n);
     const float4 g4 = fxor4(G, a.sy);
     if (!EDGE) {
         if (a.own) {
-            *reinterpret_cast<float4*>(a.oc + (size_t)q * a.P) = G;
-            if (top) *reinterpret_cast<float4*>(a.oc) = g4;
-            if (bot) *reinterpret_cast<float4*>(a.oc + (size_t)(a.n + 1) * a.P) = g4;
+            st4(a.oc + (size_t)q * a.P, G);
+            if (top) st4(a.oc, g4);
+            if (bot) st4(a.oc + (size_t)(a.n + 1) * a.P, g4);
         }
         return;
     }
@@ -421,29 +455,29 @@ __device__ __forceinline__ void tb_store(const float4& G, int q, const TbArgs& a
         for (int side = 0; side < 3; ++side) {
             if (side == 1 && !top) continue;
             if (side == 2 && !bot) continue;
-            float* o = a.oc + (side == 0 ? (size_t)q : side == 1 ? (size_t)0 : (size_t)(a.n + 1)) * a.P;
+            S* o = a.oc + (side == 0 ? (size_t)q : side == 1 ? (size_t)0 : (size_t)(a.n + 1)) * a.P;
             const float4 val = side == 0 ? G : g4;
             if (a.last >= 3) {
-                *reinterpret_cast<float4*>(o) = val;
+                st4(o, val);
             } else {
-                o[0] = val.x;
-                if (a.last >= 1) o[1] = val.y;
-                if (a.last >= 2) o[2] = val.z;
+                st1(o, val.x);
+                if (a.last >= 1) st1(o + 1, val.y);
+                if (a.last >= 2) st1(o + 2, val.z);
             }
         }
     }
     if (a.is_lg) {                       // ghost column 0 (+ corners): only window 0 has k == -1
-        a.oc[(size_t)q * a.P + 3] = G.w;
+        st1(a.oc + (size_t)q * a.P + 3, G.w);
         const float corner = 0.5f * (fxor(v1, a.sy) + fxor(v1, a.sx));
-        if (top) a.oc[3] = corner;
-        if (bot) a.oc[(size_t)(a.n + 1) * a.P + 3] = corner;
+        if (top) st1(a.oc + 3, corner);
+        if (bot) st1(a.oc + (size_t)(a.n + 1) * a.P + 3, corner);
     }
     if (a.st_rg) {                       // ghost column n+1 (+ corners)
         const float gv = a.cg == 0 ? G.x : a.cg == 1 ? G.y : a.cg == 2 ? G.z : G.w;
-        a.oc[(size_t)q * a.P + a.cg] = gv;
+        st1(a.oc + (size_t)q * a.P + a.cg, gv);
         const float corner = 0.5f * (fxor(vn, a.sy) + fxor(vn, a.sx));
-        if (top) a.oc[a.cg] = corner;
-        if (bot) a.oc[(size_t)(a.n + 1) * a.P + a.cg] = corner;
+        if (top) st1(a.oc + a.cg, corner);
+        if (bot) st1(a.oc + (size_t)(a.n + 1) * a.P + a.cg, corner);
     }
 }
 
@@ -463,16 +497,16 @@ __device__ __forceinline__ void tb_qshift(float4 (&Q)[N])
 // WALL = false: the strip is far enough from rows 0 / n+1 that every row a later
 // stage needs is interior -- a branch-free body.  WALL = true: per-stage checks,
 // ghost rows of each stage regenerated from its rows 1 / n.
-template <int T, int DIVMODE, bool EDGE, bool WALL, int PH>
+template <int T, int DIVMODE, bool EDGE, bool WALL, int PH, typename S>
 __device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T + 1], float4 (&PX)[3], float4 (&PQ)[3],
-                                        const TbArgs& a)
+                                        const TbArgs<S>& a)
 {
     constexpr int UP = PH % 3, ME = (PH + 1) % 3, FR = (PH + 2) % 3;
     W[0][FR] = PX[PH];                                   // stage 0: row t of x (loaded three steps ago)
     Q[0] = PQ[PH];
     if (t + 3 <= a.t_ld && a.ld_ok) {                    // refill the slot with row t+3: three steps of
-        PX[PH] = *reinterpret_cast<const float4*>(a.xc + (size_t)(t + 3) * a.P);   // arithmetic cover the
-        PQ[PH] = *reinterpret_cast<const float4*>(a.rc + (size_t)(t + 3) * a.P);   // HBM latency
+        PX[PH] = ld4(a.xc + (size_t)(t + 3) * a.P);      // arithmetic cover the HBM latency
+        PQ[PH] = ld4(a.rc + (size_t)(t + 3) * a.P);
     }
 #pragma unroll
     for (int s = 1; s <= T; ++s) {
@@ -506,8 +540,8 @@ __device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T 
     tb_qshift<T, T + 1>(Q);
 }
 
-template <int T, int DIVMODE, bool EDGE, bool WALL>
-__device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs& a)
+template <int T, int DIVMODE, bool EDGE, bool WALL, typename S>
+__device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs<S>& a)
 {
     float4 W[T][3], Q[T + 1], PX[3], PQ[3];
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -520,8 +554,8 @@ __device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs& a)
         PX[d] = zero4;
         PQ[d] = zero4;
         if (t0 + d <= a.t_ld && a.ld_ok) {
-            PX[d] = *reinterpret_cast<const float4*>(a.xc + (size_t)(t0 + d) * a.P);
-            PQ[d] = *reinterpret_cast<const float4*>(a.rc + (size_t)(t0 + d) * a.P);
+            PX[d] = ld4(a.xc + (size_t)(t0 + d) * a.P);
+            PQ[d] = ld4(a.rc + (size_t)(t0 + d) * a.P);
         }
     }
     // whole triples only: up to two surplus steps load nothing (t > t_ld) and store nothing (q >= q_hi)
@@ -535,13 +569,13 @@ __device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs& a)
 // second launch-bound argument = waves per SIMD the register allocator must leave room for.
 // blockIdx.z picks one of up to three independent solves of the same shape (u, v and density
 // diffusion): more waves per launch, hence taller strips and less pipeline-fill redundancy.
-template <int T, int DIVMODE>
+template <int T, int DIVMODE, typename S>
 __global__ __launch_bounds__(256, (T <= 4 ? 3 : 2)) void k_jacobi_tb(TbBatch batch, int pitch, int n, int row_lo, int row_hi,
                                                                     int rb)
 {
-    const float* __restrict__ x = batch.x[blockIdx.z];
-    const float* __restrict__ x0 = batch.x0[blockIdx.z];
-    float* __restrict__ out = batch.out[blockIdx.z];
+    const S* __restrict__ x = static_cast<const S*>(batch.x[blockIdx.z]);
+    const S* __restrict__ x0 = static_cast<const S*>(batch.x0[blockIdx.z]);
+    S* __restrict__ out = static_cast<S*>(batch.out[blockIdx.z]);
     const float alpha = batch.alpha[blockIdx.z], beta = batch.beta[blockIdx.z];
     const double yd = batch.yd[blockIdx.z];
     const int b = batch.b[blockIdx.z];
@@ -549,7 +583,7 @@ __global__ __launch_bounds__(256, (T <= 4 ? 3 : 2)) void k_jacobi_tb(TbBatch bat
     constexpr int VS = 64 - 2 * HL;
     const int lane = threadIdx.x & 63;
     const int strip = blockIdx.y * 4 + (threadIdx.x >> 6);
-    TbArgs a;
+    TbArgs<S> a;
     a.yd = yd;
     a.q_lo = row_lo + strip * rb;                        // this wave's output rows [q_lo, q_hi)
     if (a.q_lo >= row_hi) return;                        // wave-uniform
@@ -596,17 +630,18 @@ __global__ __launch_bounds__(256, (T <= 4 ? 3 : 2)) void k_jacobi_tb(TbBatch bat
 // a5  advect (FluidSequential.c:107-141): one thread per cell; the wave reads
 // 64 consecutive u,v (coalesced) and gathers the four bilinear taps of d0.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_advect(float* __restrict__ d, const float* __restrict__ d0,
-                                                const float* __restrict__ u, const float* __restrict__ v,
-                                                int pitch, int n, int row_lo, int row_hi, float dt0, int b)
+template <typename S>
+__global__ __launch_bounds__(256) void k_advect(S* __restrict__ d, const S* __restrict__ d0, const S* __restrict__ u,
+                                                const S* __restrict__ v, int pitch, int n, int row_lo, int row_hi,
+                                                float dt0, int b)
 {
     const int j = 1 + blockIdx.x * 256 + threadIdx.x;
     const int i = row_lo + blockIdx.y;
     if (j > n || i >= row_hi) return;
     const size_t P = (size_t)pitch;
     const size_t c = (size_t)i * P + XOFF + j;
-    float px = (float)j - dt0 * u[c];
-    float py = (float)i - dt0 * v[c];
+    float px = (float)j - dt0 * ld1(u + c);
+    float py = (float)i - dt0 * ld1(v + c);
     const float hi = (float)n + 0.5f;
     if (px < 0.5f) px = 0.5f;
     if (px > hi) px = hi;
@@ -615,11 +650,11 @@ __global__ __launch_bounds__(256) void k_advect(float* __restrict__ d, const flo
     const int j0 = (int)px, i0 = (int)py;
     const float s1 = px - (float)j0, s0 = 1.0f - s1;
     const float t1 = py - (float)i0, t0 = 1.0f - t1;
-    const float* q = d0 + (size_t)i0 * P + XOFF + j0;
-    const float a = t0 * q[0] + t1 * q[P];
-    const float e = t0 * q[1] + t1 * q[P + 1];
+    const S* q = d0 + (size_t)i0 * P + XOFF + j0;
+    const float a = t0 * ld1(q) + t1 * ld1(q + P);
+    const float e = t0 * ld1(q + 1) + t1 * ld1(q + P + 1);
     const float val = s0 * a + s1 * e;
-    d[c] = val;
+    st1(d + c, val);
     emit_ghosts(d, P, n, b, j, i, val);
 }
 
@@ -628,9 +663,10 @@ __global__ __launch_bounds__(256) void k_advect(float* __restrict__ d, const flo
 // div = (-0.5f*h) * (((uR - uL) + vD) - vU), p = 0, set_bnd(0) on both: the
 // ghosts of p are 0 as well, so p is zeroed on whole rows incl. ghost rows.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_divergence(const float* __restrict__ u, const float* __restrict__ v,
-                                                    float* __restrict__ p, float* __restrict__ div, int pitch,
-                                                    int n, int row_lo, int row_hi, float h)
+template <typename S>
+__global__ __launch_bounds__(256) void k_divergence(const S* __restrict__ u, const S* __restrict__ v, S* __restrict__ p,
+                                                    S* __restrict__ div, int pitch, int n, int row_lo, int row_hi,
+                                                    float h)
 {
     const int j = 1 + blockIdx.x * 256 + threadIdx.x;
     const int i = row_lo + blockIdx.y;
@@ -638,13 +674,13 @@ __global__ __launch_bounds__(256) void k_divergence(const float* __restrict__ u,
     const size_t P = (size_t)pitch;
     const size_t c = (size_t)i * P + XOFF + j;
     const float scale = -0.5f * h;
-    float g = u[c + 1] - u[c - 1];
-    g = g + v[c + P];
-    g = g - v[c - P];
+    float g = ld1(u + c + 1) - ld1(u + c - 1);
+    g = g + ld1(v + c + P);
+    g = g - ld1(v + c - P);
     const float val = scale * g;
-    div[c] = val;
+    st1(div + c, val);
     emit_ghosts(div, P, n, 0, j, i, val);
-    p[c] = 0.0f;
+    st1(p + c, 0.0f);
     emit_ghosts(p, P, n, 0, j, i, 0.0f);
 }
 
@@ -652,21 +688,21 @@ __global__ __launch_bounds__(256) void k_divergence(const float* __restrict__ u,
 // a7  pressure-gradient subtraction (FluidSequential.c:161-173):
 // u -= (0.5f*(pR-pL))/h ; v -= (0.5f*(pD-pU))/h ; set_bnd(1,u), set_bnd(2,v).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_subtract_gradient(float* __restrict__ u, float* __restrict__ v,
-                                                           const float* __restrict__ p, int pitch, int n,
-                                                           int row_lo, int row_hi, float h)
+template <typename S>
+__global__ __launch_bounds__(256) void k_subtract_gradient(S* __restrict__ u, S* __restrict__ v, const S* __restrict__ p,
+                                                           int pitch, int n, int row_lo, int row_hi, float h)
 {
     const int j = 1 + blockIdx.x * 256 + threadIdx.x;
     const int i = row_lo + blockIdx.y;
     if (j > n || i >= row_hi) return;
     const size_t P = (size_t)pitch;
     const size_t c = (size_t)i * P + XOFF + j;
-    const float gx = 0.5f * (p[c + 1] - p[c - 1]);
-    const float gy = 0.5f * (p[c + P] - p[c - P]);
-    const float nu = u[c] - gx / h;
-    const float nv = v[c] - gy / h;
-    u[c] = nu;
-    v[c] = nv;
+    const float gx = 0.5f * (ld1(p + c + 1) - ld1(p + c - 1));
+    const float gy = 0.5f * (ld1(p + c + P) - ld1(p + c - P));
+    const float nu = ld1(u + c) - gx / h;
+    const float nv = ld1(v + c) - gy / h;
+    st1(u + c, nu);
+    st1(v + c, nv);
     emit_ghosts(u, P, n, 1, j, i, nu);
     emit_ghosts(v, P, n, 2, j, i, nv);
 }
@@ -687,32 +723,33 @@ __device__ __forceinline__ float wave_max(float m)
     return m;
 }
 
-__global__ __launch_bounds__(256) void k_absmax2(const float* __restrict__ u, const float* __restrict__ v,
-                                                 int pitch, int n, int row_lo, int row_hi,
-                                                 unsigned int* __restrict__ result)
+template <typename S>
+__global__ __launch_bounds__(256) void k_absmax2(const S* __restrict__ u, const S* __restrict__ v, int pitch, int n,
+                                                 int row_lo, int row_hi, unsigned int* __restrict__ result)
 {
     const size_t P = (size_t)pitch;
     float m = 0.0f;
     for (int i = row_lo + blockIdx.y; i < row_hi; i += gridDim.y)
         for (int j = 1 + blockIdx.x * 256 + threadIdx.x; j <= n; j += gridDim.x * 256) {
             const size_t c = (size_t)i * P + XOFF + j;
-            m = fmaxf(m, fmaxf(fabsf(u[c]), fabsf(v[c])));
+            m = fmaxf(m, fmaxf(fabsf(ld1(u + c)), fabsf(ld1(v + c))));
         }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax(result, __float_as_uint(m));
 }
 
-__global__ __launch_bounds__(256) void k_residual(const float* __restrict__ x, const float* __restrict__ x0,
-                                                  int pitch, int n, int row_lo, int row_hi, float alpha,
-                                                  float beta, unsigned int* __restrict__ result)
+template <typename S>
+__global__ __launch_bounds__(256) void k_residual(const S* __restrict__ x, const S* __restrict__ x0, int pitch, int n,
+                                                  int row_lo, int row_hi, float alpha, float beta,
+                                                  unsigned int* __restrict__ result)
 {
     const size_t P = (size_t)pitch;
     float m = 0.0f;
     for (int i = row_lo + blockIdx.y; i < row_hi; i += gridDim.y)
         for (int j = 1 + blockIdx.x * 256 + threadIdx.x; j <= n; j += gridDim.x * 256) {
             const size_t c = (size_t)i * P + XOFF + j;
-            const float nb = x[c - 1] + x[c + 1] + x[c - P] + x[c + P];
-            m = fmaxf(m, fabsf(beta * x[c] - alpha * nb - x0[c]));
+            const float nb = ld1(x + c - 1) + ld1(x + c + 1) + ld1(x + c - P) + ld1(x + c + P);
+            m = fmaxf(m, fabsf(beta * ld1(x + c) - alpha * nb - ld1(x0 + c)));
         }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax(result, __float_as_uint(m));
@@ -720,47 +757,63 @@ __global__ __launch_bounds__(256) void k_residual(const float* __restrict__ x, c
 
 // ---------------------------------------------------------------------------
 // launch wrappers (host).  Shapes are validated by the caller (fluid_solver).
+// `st` selects the field storage type the untyped pointers refer to.
 // ---------------------------------------------------------------------------
 static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
-void launch_set_bnd(hipStream_t s, float* f, int pitch, int n, int b)
+#define FLUID_BY_STORAGE(st, CALL)            \
+    do {                                      \
+        if ((st) == STORAGE_F16) {            \
+            using S = half_t;                 \
+            CALL;                             \
+        } else {                              \
+            using S = float;                  \
+            CALL;                             \
+        }                                     \
+    } while (0)
+
+void launch_set_bnd(hipStream_t s, int st, void* f, int pitch, int n, int b)
 {
-    hipLaunchKernelGGL(k_set_bnd, dim3(cdiv(n, 256)), dim3(256), 0, s, f, pitch, n, b);
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_set_bnd<S>, dim3(cdiv(n, 256)), dim3(256), 0, s, (S*)f, pitch, n, b));
 }
 
-void launch_add_source(hipStream_t s, float* x, const float* src, int pitch, int row_lo, int row_hi, float dt)
+void launch_add_source(hipStream_t s, int st, void* x, const void* src, int pitch, int row_lo, int row_hi, float dt)
 {
     const size_t total = (size_t)(row_hi - row_lo) * (pitch >> 2);
     const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_add_source, dim3(blocks ? blocks : 1), dim3(256), 0, s, x, src, pitch, row_lo, row_hi, dt);
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_add_source<S>, dim3(blocks ? blocks : 1), dim3(256), 0, s, (S*)x,
+                                            (const S*)src, pitch, row_lo, row_hi, dt));
 }
 
-void launch_jacobi(hipStream_t s, int variant, const float* x, const float* x0, float* out, int pitch, int n,
+void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void* x0, void* out, int pitch, int n,
                    int row_lo, int row_hi, float alpha, float beta, int b)
 {
     const int rows = row_hi - row_lo;
     if (rows <= 0) return;
     switch (variant) {
     case JACOBI_NAIVE:
-        hipLaunchKernelGGL(k_jacobi_naive, dim3(cdiv(n, 64), cdiv(rows, 4)), dim3(256), 0, s, x, x0, out, pitch, n,
-                           row_lo, row_hi, alpha, beta, b);
+        FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_jacobi_naive<S>, dim3(cdiv(n, 64), cdiv(rows, 4)), dim3(256), 0, s,
+                                                (const S*)x, (const S*)x0, (S*)out, pitch, n, row_lo, row_hi, alpha,
+                                                beta, b));
         break;
     case JACOBI_LDS:
-        hipLaunchKernelGGL(k_jacobi_lds, dim3(cdiv(n, LT_X), cdiv(rows, LT_Y)), dim3(256), 0, s, x, x0, out, pitch,
-                           n, row_lo, row_hi, alpha, beta, b);
+        FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_jacobi_lds<S>, dim3(cdiv(n, LT_X), cdiv(rows, LT_Y)), dim3(256), 0, s,
+                                                (const S*)x, (const S*)x0, (S*)out, pitch, n, row_lo, row_hi, alpha,
+                                                beta, b));
         break;
     default: {
         constexpr int RB = 8;
         const unsigned nvec = (n + 3) / 4;
-        hipLaunchKernelGGL(k_jacobi_stream<RB>, dim3(cdiv(nvec, 256), cdiv(rows, RB)), dim3(256), 0, s, x, x0, out,
-                           pitch, n, row_lo, row_hi, alpha, beta, b);
+        FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_jacobi_stream<RB, S>), dim3(cdiv(nvec, 256), cdiv(rows, RB)), dim3(256),
+                                                0, s, (const S*)x, (const S*)x0, (S*)out, pitch, n, row_lo, row_hi,
+                                                alpha, beta, b));
     }
     }
 }
 
 // T in {8,4,2}; batch.count solves per launch.  divmode 0: beta; 1: beta = exact reciprocal;
 // 2: beta unused, yd = RN64(1/beta).
-void launch_jacobi_tb(hipStream_t s, int T, int divmode, const TbBatch& batch, int pitch, int n, int row_lo,
+void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, const TbBatch& batch, int pitch, int n, int row_lo,
                       int row_hi, int rb)
 {
     const int rows = row_hi - row_lo;
@@ -768,7 +821,8 @@ void launch_jacobi_tb(hipStream_t s, int T, int divmode, const TbBatch& batch, i
     const int HL = (T + 3) / 4, VS = 64 - 2 * HL;
     const unsigned nvec = (n + 3) / 4;
     const dim3 grid(cdiv(nvec, VS), cdiv(cdiv(rows, rb), 4), batch.count), block(256);
-#define FLUID_TB1(TT, DD) hipLaunchKernelGGL((k_jacobi_tb<TT, DD>), grid, block, 0, s, batch, pitch, n, row_lo, row_hi, rb)
+#define FLUID_TB1(TT, DD) \
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_jacobi_tb<TT, DD, S>), grid, block, 0, s, batch, pitch, n, row_lo, row_hi, rb))
 #define FLUID_TB(TT)                     \
     if (divmode == 2) FLUID_TB1(TT, 2);  \
     else if (divmode == 1) FLUID_TB1(TT, 1); \
@@ -787,47 +841,48 @@ void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, doub
     else hipLaunchKernelGGL((k_validate_div<2>), dim3(8192), dim3(256), 0, s, beta, arg, yd, bad);
 }
 
-void launch_advect(hipStream_t s, float* d, const float* d0, const float* u, const float* v, int pitch, int n,
+void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u, const void* v, int pitch, int n,
                    int row_lo, int row_hi, float dt0, int b)
 {
     if (row_hi <= row_lo) return;
-    hipLaunchKernelGGL(k_advect, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s, d, d0, u, v, pitch, n, row_lo,
-                       row_hi, dt0, b);
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_advect<S>, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s, (S*)d,
+                                            (const S*)d0, (const S*)u, (const S*)v, pitch, n, row_lo, row_hi, dt0, b));
 }
 
-void launch_divergence(hipStream_t s, const float* u, const float* v, float* p, float* div, int pitch, int n,
+void launch_divergence(hipStream_t s, int st, const void* u, const void* v, void* p, void* div, int pitch, int n,
                        int row_lo, int row_hi, float h)
 {
     if (row_hi <= row_lo) return;
-    hipLaunchKernelGGL(k_divergence, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s, u, v, p, div, pitch, n,
-                       row_lo, row_hi, h);
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_divergence<S>, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s,
+                                            (const S*)u, (const S*)v, (S*)p, (S*)div, pitch, n, row_lo, row_hi, h));
 }
 
-void launch_subtract_gradient(hipStream_t s, float* u, float* v, const float* p, int pitch, int n, int row_lo,
+void launch_subtract_gradient(hipStream_t s, int st, void* u, void* v, const void* p, int pitch, int n, int row_lo,
                               int row_hi, float h)
 {
     if (row_hi <= row_lo) return;
-    hipLaunchKernelGGL(k_subtract_gradient, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s, u, v, p, pitch, n,
-                       row_lo, row_hi, h);
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_subtract_gradient<S>, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s,
+                                            (S*)u, (S*)v, (const S*)p, pitch, n, row_lo, row_hi, h));
 }
 
-void launch_absmax2(hipStream_t s, const float* u, const float* v, int pitch, int n, int row_lo, int row_hi,
+void launch_absmax2(hipStream_t s, int st, const void* u, const void* v, int pitch, int n, int row_lo, int row_hi,
                     unsigned int* result)
 {
     if (row_hi <= row_lo) return;
     const unsigned gy = (unsigned)(row_hi - row_lo) < 512u ? (unsigned)(row_hi - row_lo) : 512u;
     const unsigned gx = cdiv(n, 256) < 8u ? cdiv(n, 256) : 8u;
-    hipLaunchKernelGGL(k_absmax2, dim3(gx, gy), dim3(256), 0, s, u, v, pitch, n, row_lo, row_hi, result);
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_absmax2<S>, dim3(gx, gy), dim3(256), 0, s, (const S*)u, (const S*)v, pitch,
+                                            n, row_lo, row_hi, result));
 }
 
-void launch_residual(hipStream_t s, const float* x, const float* x0, int pitch, int n, int row_lo, int row_hi,
+void launch_residual(hipStream_t s, int st, const void* x, const void* x0, int pitch, int n, int row_lo, int row_hi,
                      float alpha, float beta, unsigned int* result)
 {
     if (row_hi <= row_lo) return;
     const unsigned gy = (unsigned)(row_hi - row_lo) < 512u ? (unsigned)(row_hi - row_lo) : 512u;
     const unsigned gx = cdiv(n, 256) < 8u ? cdiv(n, 256) : 8u;
-    hipLaunchKernelGGL(k_residual, dim3(gx, gy), dim3(256), 0, s, x, x0, pitch, n, row_lo, row_hi, alpha, beta,
-                       result);
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_residual<S>, dim3(gx, gy), dim3(256), 0, s, (const S*)x, (const S*)x0, pitch,
+                                            n, row_lo, row_hi, alpha, beta, result));
 }
 
 }  // namespace fluid

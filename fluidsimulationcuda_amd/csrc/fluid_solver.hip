@@ -55,11 +55,14 @@ constexpr int kMaxN = 1 << 20;   // index arithmetic is size_t; advect's clamp c
 struct fluid_ctx {
     int n = 0, w = 0, pitch = 0;
     size_t field_floats = 0;
-    float* arena = nullptr;
+    char* arena = nullptr;
     bool own_arena = false;
+    int st = fluid::STORAGE_F32;          // field storage type
+    size_t esz = 4;                       // bytes per stored element
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    float* f[FLUID_NFIELDS] = {};
+    void* f[FLUID_NFIELDS] = {};
+    size_t field_bytes = 0;
     unsigned int* d_scalar = nullptr;     // device word for the reductions
     unsigned int* h_scalar = nullptr;     // pinned host mirror
     hipEvent_t scalar_ready = nullptr;    // recorded behind the scalar's device-to-host copy
@@ -83,6 +86,7 @@ struct fluid_ctx {
     long long sweeps = 0, pending_sweeps = 0;
 
     bool valid_field(int id) const { return id >= 0 && id < FLUID_NFIELDS; }
+    void* row(int id, int r) const { return static_cast<char*>(f[id]) + (size_t)r * pitch * esz; }
     int lo_all() const { return own0 - (rank == 0 ? 1 : 0); }          // owned rows incl. ghost row
     int hi_all() const { return own1 + (rank == nranks - 1 ? 1 : 0); }
 };
@@ -263,7 +267,7 @@ int op_add_source(fluid_ctx* c, int x, int s, float dt)
     rows(c, reach, &lo, &hi);
     if (lo == 1) lo = 0;                     // wall rows are cells like any other here (FluidSequential.c:78-82)
     if (hi == c->n + 1) hi = c->n + 2;
-    TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->f[x], c->f[s], c->pitch, lo, hi, dt));
+    TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->st, c->f[x], c->f[s], c->pitch, lo, hi, dt));
     wrote(c, x, reach);
     return FLUID_OK;
 }
@@ -345,7 +349,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         if (T == 1) {
             const int v = c->variant == fluid::JACOBI_TB ? (small ? fluid::JACOBI_NAIVE : fluid::JACOBI_STREAM) : c->variant;
             for (int j = 0; j < count; ++j)
-                fluid::launch_jacobi(c->stream, v, c->f[cur[j]], c->f[sv[j].x0], c->f[nxt[j]], c->pitch, c->n, lo, hi,
+                fluid::launch_jacobi(c->stream, c->st, v, c->f[cur[j]], c->f[sv[j].x0], c->f[nxt[j]], c->pitch, c->n, lo, hi,
                                      sv[j].alpha, sv[j].beta, sv[j].b);
         } else {
             // one launch per group of solves that share a division mode (normally: all of them)
@@ -376,7 +380,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                     rb = (int)(((long long)(hi - lo) * windows * m + want - 1) / want);
                     rb = std::max(2 * T, std::min(rb, T >= 8 ? 160 : 192));
                 }
-                fluid::launch_jacobi_tb(c->stream, T, divmode[first], bt, c->pitch, c->n, lo, hi, rb);
+                fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], bt, c->pitch, c->n, lo, hi, rb);
                 first = last;
             }
         }
@@ -415,7 +419,7 @@ int vmax_begin(fluid_ctx* c, int u, int v)
 {
     if (c->nranks == 1) return FLUID_OK;
     HIP_TRY(hipMemsetAsync(c->d_scalar, 0, sizeof(unsigned), c->stream));
-    fluid::launch_absmax2(c->stream, c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, c->d_scalar);
+    fluid::launch_absmax2(c->stream, c->st, c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, c->d_scalar);
     TRY(exchange(c, FLUID_XCHG_MAX_BEGIN, {}, 0));       // in-place MAX over ranks on the device scalar
     HIP_TRY(hipMemcpyAsync(c->h_scalar, c->d_scalar, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->scalar_ready, c->stream));
@@ -449,7 +453,7 @@ int op_advect(fluid_ctx* c, int b, int d, int d0, int u, int v, float dt)
     if (d == d0 || d == u || d == v) return fail(FLUID_E_INVALID, "advect: output must not alias an input");
     const float dt0 = dt * (float)c->n;
     TIMED(c, FLUID_TIME_ADVECTION,
-          fluid::launch_advect(c->stream, c->f[d], c->f[d0], c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, dt0, b));
+          fluid::launch_advect(c->stream, c->st, c->f[d], c->f[d0], c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, dt0, b));
     wrote(c, d, 0);
     return FLUID_OK;
 }
@@ -468,13 +472,13 @@ int op_divergence(fluid_ctx* c, int u, int v, int p, int div, int want = 0)
         TRY(need(c, {u, v}, reach + 1));
         // p = 0 on every row the solve may read: one row further out than the divergence
         const int z0 = std::max(0, c->own0 - reach - 1), z1 = std::min(c->w, c->own1 + reach + 1);
-        HIP_TRY(hipMemsetAsync(c->f[p] + (size_t)z0 * c->pitch, 0, (size_t)(z1 - z0) * c->pitch * sizeof(float), c->stream));
+        HIP_TRY(hipMemsetAsync(c->row(p, z0), 0, (size_t)(z1 - z0) * c->pitch * c->esz, c->stream));
     }
     int lo, hi;
     rows(c, reach, &lo, &hi);
     // ghost rows/columns of p and div are written by the fused boundary of the edge rows
     TIMED(c, FLUID_TIME_DIVERGENCE,
-          fluid::launch_divergence(c->stream, c->f[u], c->f[v], c->f[p], c->f[div], c->pitch, c->n, lo, hi, h));
+          fluid::launch_divergence(c->stream, c->st, c->f[u], c->f[v], c->f[p], c->f[div], c->pitch, c->n, lo, hi, h));
     wrote(c, div, reach);
     wrote(c, p, reach + 1);
     return FLUID_OK;
@@ -486,7 +490,7 @@ int op_subtract_gradient(fluid_ctx* c, int u, int v, int p)
     const float h = 1.0f / (float)c->n;
     TRY(need(c, {p}, 1));
     TIMED(c, FLUID_TIME_PROJECTION,
-          fluid::launch_subtract_gradient(c->stream, c->f[u], c->f[v], c->f[p], c->pitch, c->n, c->own0, c->own1, h));
+          fluid::launch_subtract_gradient(c->stream, c->st, c->f[u], c->f[v], c->f[p], c->pitch, c->n, c->own0, c->own1, h));
     wrote(c, u, 0);
     wrote(c, v, 0);
     return FLUID_OK;
@@ -594,7 +598,7 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
 int zero_sources(fluid_ctx* c)
 {
     for (int id : {FLUID_U_PREV, FLUID_V_PREV, FLUID_DENS_PREV}) {
-        HIP_TRY(hipMemsetAsync(c->f[id], 0, c->field_floats * sizeof(float), c->stream));
+        HIP_TRY(hipMemsetAsync(c->f[id], 0, c->field_bytes, c->stream));
         wrote(c, id, kEverywhere);
     }
     return FLUID_OK;
@@ -604,16 +608,34 @@ int copy_rows(fluid_ctx* c, int field, float* host, const float* chost, int row_
 {
     if (row_lo < 0 || row_hi > c->w || row_lo > row_hi) return fail(FLUID_E_INVALID, "bad row range");
     if (row_lo == row_hi) return FLUID_OK;
-    float* dev = c->f[field] + (size_t)row_lo * c->pitch + XOFF;
-    const size_t hp = (size_t)c->w * sizeof(float), dp = (size_t)c->pitch * sizeof(float);
-    const size_t rows = (size_t)(row_hi - row_lo);
-    if (to_device) {
-        c->reach[field] = 0;     // the caller vouches only for its own rows
-        HIP_TRY(hipMemcpy2DAsync(dev, dp, chost + (size_t)row_lo * c->w, hp, hp, rows, hipMemcpyHostToDevice, c->stream));
+    char* dev = static_cast<char*>(c->row(field, row_lo)) + (size_t)XOFF * c->esz;
+    const size_t rows = (size_t)(row_hi - row_lo), w = (size_t)c->w;
+    const size_t dp = (size_t)c->pitch * c->esz;
+    if (to_device) c->reach[field] = 0;     // the caller vouches only for its own rows
+    if (c->st == fluid::STORAGE_F32) {
+        const size_t hp = w * sizeof(float);
+        if (to_device)
+            HIP_TRY(hipMemcpy2DAsync(dev, dp, chost + (size_t)row_lo * w, hp, hp, rows, hipMemcpyHostToDevice, c->stream));
+        else
+            HIP_TRY(hipMemcpy2DAsync(host + (size_t)row_lo * w, hp, dev, dp, hp, rows, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return FLUID_OK;
     }
-    else
-        HIP_TRY(hipMemcpy2DAsync(host + (size_t)row_lo * c->w, hp, dev, dp, hp, rows, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // fp16 storage: the ABI's host arrays stay float; convert through a host staging buffer
+    // (round to nearest even on the way in, exact on the way out)
+    std::vector<fluid::half_t> stage(rows * w);
+    const size_t hp = w * sizeof(fluid::half_t);
+    if (to_device) {
+        const float* src = chost + (size_t)row_lo * w;
+        for (size_t k = 0; k < rows * w; ++k) stage[k] = (fluid::half_t)src[k];
+        HIP_TRY(hipMemcpy2DAsync(dev, dp, stage.data(), hp, hp, rows, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } else {
+        HIP_TRY(hipMemcpy2DAsync(stage.data(), hp, dev, dp, hp, rows, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        float* dst = host + (size_t)row_lo * w;
+        for (size_t k = 0; k < rows * w; ++k) dst[k] = (float)stage[k];
+    }
     return FLUID_OK;
 }
 
@@ -645,12 +667,15 @@ int fluid_layout(int N, int* pitch, int* xoff, size_t* field_floats)
     return FLUID_OK;
 }
 
-size_t fluid_arena_bytes(int N)
+size_t fluid_arena_bytes_ex(int N, int storage)
 {
     size_t ff = 0;
     if (fluid_layout(N, nullptr, nullptr, &ff) != FLUID_OK) return 0;
-    return ff * FLUID_NFIELDS * sizeof(float) + kControlBytes;
+    if (storage != FLUID_STORAGE_F32 && storage != FLUID_STORAGE_F16) return 0;
+    return ff * FLUID_NFIELDS * fluid::storage_bytes(storage) + kControlBytes;
 }
+
+size_t fluid_arena_bytes(int N) { return fluid_arena_bytes_ex(N, FLUID_STORAGE_F32); }
 
 int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
 {
@@ -662,6 +687,8 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
     if (cfg->rank < 0 || cfg->rank >= P) return fail(FLUID_E_INVALID, "rank %d outside [0,%d)", cfg->rank, P);
     if (cfg->jacobi_variant < 0 || cfg->jacobi_variant >= fluid::JACOBI_VARIANTS)
         return fail(FLUID_E_INVALID, "unknown Jacobi variant %d", cfg->jacobi_variant);
+    if (cfg->storage != FLUID_STORAGE_F32 && cfg->storage != FLUID_STORAGE_F16)
+        return fail(FLUID_E_INVALID, "unknown storage type %d", cfg->storage);
     if (P > 1 && n / P < 2) return fail(FLUID_E_INVALID, "N=%d is too small for %d row slabs (need >= 2 rows each)", n, P);
     fluid_ctx* c = new (std::nothrow) fluid_ctx;
     if (!c) return fail(FLUID_E_NOMEM, "out of host memory");
@@ -669,6 +696,9 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
     c->w = n + 2;
     c->pitch = fluid::pitch_for(n);
     c->field_floats = (size_t)c->w * c->pitch;
+    c->st = cfg->storage;
+    c->esz = fluid::storage_bytes(c->st);
+    c->field_bytes = c->field_floats * c->esz;
     c->variant = cfg->jacobi_variant;
     c->rank = cfg->rank;
     c->nranks = P;
@@ -682,13 +712,13 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
     // 1024-row slab; shallower on short slabs
     const int want = cfg->halo > 0 ? cfg->halo : std::max(4, std::min(42, base / 8));
     c->halo = P > 1 ? std::max(1, std::min(want, base - 1)) : 1;
-    const size_t bytes = c->field_floats * FLUID_NFIELDS * sizeof(float) + kControlBytes;
+    const size_t bytes = c->field_bytes * FLUID_NFIELDS + kControlBytes;
     int rc = FLUID_OK;
     auto bail = [&](int code) { fluid_destroy(c); return code; };
     if (cfg->arena) {
         if (cfg->arena_bytes < bytes) return bail(fail(FLUID_E_INVALID, "arena too small: %zu < %zu", cfg->arena_bytes, bytes));
         if (((uintptr_t)cfg->arena & 255u) != 0) return bail(fail(FLUID_E_INVALID, "arena must be 256-byte aligned"));
-        c->arena = (float*)cfg->arena;
+        c->arena = (char*)cfg->arena;
     } else {
         hipError_t e = hipMalloc((void**)&c->arena, bytes);
         if (e != hipSuccess) return bail(fail(e == hipErrorOutOfMemory ? FLUID_E_NOMEM : FLUID_E_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)));
@@ -701,7 +731,7 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
         if (e != hipSuccess) return bail(fail(FLUID_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
         c->own_stream = true;
     }
-    for (int k = 0; k < FLUID_NFIELDS; ++k) c->f[k] = c->arena + (size_t)k * c->field_floats;
+    for (int k = 0; k < FLUID_NFIELDS; ++k) c->f[k] = c->arena + (size_t)k * c->field_bytes;
     auto hip_ok = [&](hipError_t e, const char* what) {
         if (e == hipSuccess) return true;
         rc = fail(e == hipErrorOutOfMemory ? FLUID_E_NOMEM : FLUID_E_HIP, "%s: %s", what, hipGetErrorString(e));
@@ -714,7 +744,7 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
             c->num_cu = cus;
     }
     if (!hip_ok(hipMemsetAsync(c->arena, 0, bytes, c->stream), "hipMemsetAsync(arena)")) return bail(rc);
-    c->d_scalar = reinterpret_cast<unsigned int*>(c->arena + c->field_floats * FLUID_NFIELDS);   // RCCL-addressable
+    c->d_scalar = reinterpret_cast<unsigned int*>(c->arena + c->field_bytes * FLUID_NFIELDS);   // RCCL-addressable
     if (!hip_ok(hipHostMalloc((void**)&c->h_scalar, 256, hipHostMallocDefault), "hipHostMalloc")) return bail(rc);
     if (!hip_ok(hipEventCreateWithFlags(&c->scalar_ready, hipEventDisableTiming), "hipEventCreate")) return bail(rc);
     if (!hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return bail(rc);
@@ -814,7 +844,7 @@ int fluid_fill(fluid_ctx* c, int field, float value)
     TRY(check_ctx(c));
     TRY(check_fields(c, {field}));
     if (value == 0.0f && !std::signbit(value)) {
-        HIP_TRY(hipMemsetAsync(c->f[field], 0, c->field_floats * sizeof(float), c->stream));
+        HIP_TRY(hipMemsetAsync(c->f[field], 0, c->field_bytes, c->stream));
         wrote(c, field, kEverywhere);
         return FLUID_OK;
     }
@@ -906,7 +936,7 @@ int fluid_op_set_bnd(fluid_ctx* c, int b, int x)
     TRY(check_fields(c, {x}));
     if (b < 0 || b > 2) return fail(FLUID_E_INVALID, "b must be 0, 1 or 2");
     if (c->nranks != 1) return fail(FLUID_E_INVALID, "fluid_op_set_bnd is a whole-grid operator (1 GPU)");
-    fluid::launch_set_bnd(c->stream, c->f[x], c->pitch, c->n, b);
+    fluid::launch_set_bnd(c->stream, c->st, c->f[x], c->pitch, c->n, b);
     HIP_TRY(hipGetLastError());
     return FLUID_OK;
 }
@@ -929,7 +959,7 @@ int fluid_op_jacobi_sweep(fluid_ctx* c, int b, int x, int x0, int out, float alp
     if (out == x || out == x0) return fail(FLUID_E_INVALID, "jacobi_sweep: out must not alias an input");
     TRY(need(c, {x}, 1));
     const int v1 = c->variant == fluid::JACOBI_TB ? fluid::JACOBI_STREAM : c->variant;   // one sweep: nothing to block
-    fluid::launch_jacobi(c->stream, v1, c->f[x], c->f[x0], c->f[out], c->pitch, c->n, c->own0, c->own1, alpha, beta, b);
+    fluid::launch_jacobi(c->stream, c->st, v1, c->f[x], c->f[x0], c->f[out], c->pitch, c->n, c->own0, c->own1, alpha, beta, b);
     wrote(c, out, 0);
     HIP_TRY(hipGetLastError());
     return FLUID_OK;
@@ -981,7 +1011,7 @@ int fluid_residual(fluid_ctx* c, int x, int x0, float alpha, float beta, float* 
     if (!out) return fail(FLUID_E_INVALID, "null pointer");
     TRY(need(c, {x}, 1));
     HIP_TRY(hipMemsetAsync(c->d_scalar, 0, sizeof(unsigned), c->stream));
-    fluid::launch_residual(c->stream, c->f[x], c->f[x0], c->pitch, c->n, c->own0, c->own1, alpha, beta, c->d_scalar);
+    fluid::launch_residual(c->stream, c->st, c->f[x], c->f[x0], c->pitch, c->n, c->own0, c->own1, alpha, beta, c->d_scalar);
     TRY(reduce_to_host(c, out));
     return exchange(c, FLUID_XCHG_MAX, {}, 0, out);
 }
@@ -992,7 +1022,7 @@ int fluid_absmax_velocity(fluid_ctx* c, int u, int v, float* out)
     TRY(check_fields(c, {u, v}));
     if (!out) return fail(FLUID_E_INVALID, "null pointer");
     HIP_TRY(hipMemsetAsync(c->d_scalar, 0, sizeof(unsigned), c->stream));
-    fluid::launch_absmax2(c->stream, c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, c->d_scalar);
+    fluid::launch_absmax2(c->stream, c->st, c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, c->d_scalar);
     TRY(reduce_to_host(c, out));
     return exchange(c, FLUID_XCHG_MAX, {}, 0, out);
 }

@@ -141,7 +141,8 @@ class SlabSolver(FluidSolver):
     RCCL can address it; kernels run on torch's current stream so the
     collectives order against them without host synchronisation."""
 
-    def __init__(self, n, rank=None, nranks=None, halo=0, jacobi=capi.JACOBI_TB, device=None, group=None):
+    def __init__(self, n, rank=None, nranks=None, halo=0, jacobi=capi.JACOBI_TB, device=None, group=None,
+                 storage=capi.STORAGE_F32, params=None):
         if rank is None:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         if nranks is None:
@@ -152,35 +153,36 @@ class SlabSolver(FluidSolver):
         if self.device.type != "cuda":
             raise RuntimeError("SlabSolver computes with HIP kernels only; got device %s" % device)
         L = capi.lib()
-        nbytes = L.fluid_arena_bytes(n)
+        nbytes = L.fluid_arena_bytes_ex(n, storage)
         if nbytes == 0:
-            capi.check(capi.E_INVALID)
+            raise ValueError("bad N or storage type")
         import ctypes as C
         pitch, xoff, ff = C.c_int(), C.c_int(), C.c_size_t()
         capi.check(L.fluid_layout(n, C.byref(pitch), C.byref(xoff), C.byref(ff)))
         self.pitch, self.xoff = pitch.value, xoff.value
         with torch.cuda.device(self.device):
-            self.arena = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.device)
+            self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
             # a real (non-null) stream: handle 0 would mean "library-owned stream"
             # to fluid_create_ex, and nothing would order RCCL against the kernels
             self.torch_stream = torch.cuda.Stream(device=self.device)
             torch.cuda.synchronize(self.device)        # the zero-fill ran on torch's default stream
             super().__init__(n, rank=rank, nranks=nranks, halo=halo, jacobi=jacobi,
                              stream=self.torch_stream.cuda_stream,
-                             arena_ptr=self.arena.data_ptr(), arena_bytes=nbytes)
-        self._ff = ff.value
-        self._views = [self.arena[k * ff.value:(k + 1) * ff.value].view(n + 2, self.pitch)
+                             arena_ptr=self.arena.data_ptr(), arena_bytes=nbytes, storage=storage, params=params)
+        esz, dt = (2, torch.float16) if storage == capi.STORAGE_F16 else (4, torch.float32)
+        self._fb = ff.value * esz           # bytes per field
+        self._views = [self.arena[k * self._fb:(k + 1) * self._fb].view(dt).view(n + 2, self.pitch)
                        for k in range(capi.NFIELDS)]
         self.exchange = None
         if nranks > 1:
             self.exchange = TorchExchange(self.field_tensor, n, rank, nranks, group, stream=self.torch_stream)
-            off = (self.scalar_ptr() - self.arena.data_ptr()) // 4
-            self.exchange.scalar = self.arena[off:off + 1]
+            off = self.scalar_ptr() - self.arena.data_ptr()
+            self.exchange.scalar = self.arena[off:off + 4].view(torch.float32)
             self.set_exchange(self.exchange)
 
     def field_tensor(self, fid):
         """[n+2, pitch] view of the buffer field `fid` occupies right now."""
-        slot, rem = divmod(self.field_ptr(fid) - self.arena.data_ptr(), 4 * self._ff)
+        slot, rem = divmod(self.field_ptr(fid) - self.arena.data_ptr(), self._fb)
         assert rem == 0 and 0 <= slot < capi.NFIELDS
         return self._views[slot]
 

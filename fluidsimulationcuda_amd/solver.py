@@ -35,11 +35,12 @@ class FluidSolver:
     """Six resident fields + scratch on one GPU (or one row slab of several)."""
 
     def __init__(self, n, rank=0, nranks=1, halo=0, jacobi=capi.JACOBI_TB, stream=None,
-                 arena_ptr=None, arena_bytes=0, params=None):
+                 arena_ptr=None, arena_bytes=0, params=None, storage=capi.STORAGE_F32):
         self._h = C.c_void_p()
         self.n = int(n)
+        self.storage = storage
         cfg = capi.Config(n=self.n, rank=rank, nranks=nranks, halo=halo, jacobi_variant=jacobi,
-                          stream=stream, arena=arena_ptr, arena_bytes=arena_bytes)
+                          stream=stream, arena=arena_ptr, arena_bytes=arena_bytes, storage=storage)
         capi.check(capi.lib().fluid_create_ex(C.byref(cfg), C.byref(self._h)))
         lo, hi = C.c_int(), C.c_int()
         capi.check(capi.lib().fluid_owned_rows(self._h, C.byref(lo), C.byref(hi)))

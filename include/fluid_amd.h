@@ -94,13 +94,21 @@ typedef struct fluid_config {
     int halo;           /* Jacobi ghost-zone depth between exchanges (0 = default)      */
     int jacobi_variant; /* FLUID_JACOBI_*                                               */
     void *stream;       /* hipStream_t to run on, or NULL for a library-owned stream    */
-    void *arena;        /* device memory of fluid_arena_bytes(n) bytes, or NULL to hipMalloc */
+    void *arena;        /* device memory of fluid_arena_bytes_ex(n, storage) bytes, or NULL to hipMalloc */
     size_t arena_bytes;
+    int storage;        /* FLUID_STORAGE_F32 (default; bit parity with the reference) or FLUID_STORAGE_F16 */
 } fluid_config;
 
-size_t fluid_arena_bytes(int N);
-/* Device layout of one field: W = N+2 rows of `pitch` floats, column c at
- * float index c + xoff; field f starts f*field_floats floats into the arena. */
+/* Field storage on the device.  F16 (BASELINE config "fp16 fields with fp32 Jacobi accumulate"):
+ * fields are IEEE half, every operator widens its inputs to float, computes exactly as the fp32
+ * path does, and rounds to nearest once when it stores; the fused Jacobi kernel keeps the
+ * intermediate sweeps of a launch in fp32 registers.  Host arrays at this ABI stay float. */
+enum { FLUID_STORAGE_F32 = 0, FLUID_STORAGE_F16 = 1 };
+
+size_t fluid_arena_bytes(int N);                       /* fp32 storage */
+size_t fluid_arena_bytes_ex(int N, int storage);
+/* Device layout of one field: W = N+2 rows of `pitch` elements, column c at
+ * element index c + xoff; field f starts f*field_floats elements into the arena. */
 int fluid_layout(int N, int *pitch, int *xoff, size_t *field_floats);
 
 int fluid_create(int N, fluid_ctx **out);                      /* 1 GPU, defaults */

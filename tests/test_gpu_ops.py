@@ -285,3 +285,72 @@ def test_temporal_blocking_reciprocal_division_is_exact(F, oracle, beta):
                     assert np.array_equal(np.isnan(got), nan)
                     assert_bit_equal(np.where(nan, 0, got), np.where(nan, 0, want),
                                      "beta=%g fast=%d %s alpha=%g" % (beta, fast, kind, alpha))
+
+
+def test_exact_cancellations_and_signed_zeros(F, oracle):
+    """Random floats almost never cancel exactly, so they never show whether
+    -0 / +0 come out as the reference's expressions produce them (x - x = +0,
+    negative * +0 = -0, -(+0) ghosts ...).  Fields drawn from a few dyadic values
+    and both zeros make such cases the norm; every operator must still match
+    bit for bit."""
+    from fluidsimulationcuda_amd import capi
+    n = 256
+    rng = np.random.default_rng(0)
+    vals = np.array([-1, -0.5, -0.25, 0.0, -0.0, 0.25, 0.5, 1], np.float32)
+
+    def q():
+        return rng.choice(vals, size=(n + 2, n + 2)).astype(np.float32)
+
+    with F.FluidSolver(n, params={capi.PARAM_TB_MIN_CELLS: 0}) as s:
+        u, v, p, d = q(), q(), q(), q()
+        s.upload(u=u, v=v, u_prev=p, v_prev=d)
+        s.computeDivergenceAndPressure("u", "v", "u_prev", "v_prev")
+        oracle.divergence(u, v, p, d)
+        assert_bit_equal(s.download("v_prev"), d, "divergence")
+        p = q()
+        s.upload(u_prev=p)
+        s.lastProject("u", "v", "u_prev")
+        oracle.subtract_gradient(u, v, p)
+        assert_bit_equal(s.download("u"), u, "gradient u")
+        assert_bit_equal(s.download("v"), v, "gradient v")
+        x, src = q(), q()
+        for dt in (0.5, -0.5, 0.0):
+            s.upload(u=x, v=src)
+            s.add_source("u", "v", dt)
+            w = x.copy()
+            oracle.add_source(w, src, dt)
+            assert_bit_equal(s.download("u"), w, "add_source dt=%g" % dt)
+        for variant in (0, 1, 2, 3):
+            s.set_jacobi_variant(variant)
+            for b in (0, 1, 2):
+                for alpha, beta in ((1.0, 4.0), (0.5, 3.0), (0.25, 2.0)):
+                    x, x0 = q(), q()
+                    s.upload(u=x, v=x0)
+                    s.diffuse(b, "u", "v", alpha, beta, 8)
+                    w = x.copy()
+                    oracle.diffuse(b, w, x0, alpha, beta, 8)
+                    assert_bit_equal(s.download("u"), w, "diffuse variant %d b=%d beta=%g" % (variant, b, beta))
+        uu, vv, d0 = q(), q(), q()
+        s.upload(u=uu, v=vv, dens_prev=d0)
+        for b in (0, 1, 2):
+            s.advect(b, "dens", "dens_prev", "u", "v", DT)
+            w = np.zeros_like(d0)
+            oracle.advect(b, w, d0, uu, vv, DT)
+            assert_bit_equal(s.download("dens"), w, "advect b=%d" % b)
+        for b in (0, 1, 2):
+            x = q()
+            s.upload(u=x)
+            s.set_bnd(b, "u")
+            w = x.copy()
+            oracle.set_bnd(b, w)
+            assert_bit_equal(s.download("u"), w, "set_bnd b=%d" % b)
+        # a whole step from such fields (zero sources: the x + dt*0 path keeps -0 where the reference does)
+        f = dict(u=q(), v=q(), dens=q())
+        s.upload(**f)
+        s.step(2)
+        z = np.zeros((n + 2, n + 2), np.float32)
+        uu, vv, dd, a0, b0, c0 = f["u"].copy(), f["v"].copy(), f["dens"].copy(), z.copy(), z.copy(), z.copy()
+        oracle.step(uu, vv, dd, a0, b0, c0)
+        oracle.step(uu, vv, dd, a0, b0, c0)
+        for name, want in (("u", uu), ("v", vv), ("dens", dd)):
+            assert_bit_equal(s.download(name), want, "two steps from coarse fields: " + name)

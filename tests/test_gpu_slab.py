@@ -117,15 +117,16 @@ def _init_fake(s, n, rank, nranks, halo, jacobi):
     pitch, xoff, ff = C.c_int(), C.c_int(), C.c_size_t()
     capi.check(L.fluid_layout(n, C.byref(pitch), C.byref(xoff), C.byref(ff)))
     s.pitch, s.xoff, s.device = pitch.value, xoff.value, torch.device("cuda", 0)
-    s.arena = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+    s.arena = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
     s.torch_stream = torch.cuda.Stream()
     torch.cuda.synchronize()
     FluidSolver.__init__(s, n, rank=rank, nranks=nranks, halo=halo, jacobi=jacobi,
                          stream=s.torch_stream.cuda_stream,
                          arena_ptr=s.arena.data_ptr(), arena_bytes=nbytes,
                          params={capi.PARAM_TB_MIN_CELLS: 0})     # fuse sweeps even on these small slabs
-    s._ff = ff.value
-    s._views = [s.arena[k * ff.value:(k + 1) * ff.value].view(n + 2, s.pitch) for k in range(capi.NFIELDS)]
+    s._fb = ff.value * 4
+    s._views = [s.arena[k * s._fb:(k + 1) * s._fb].view(torch.float32).view(n + 2, s.pitch)
+                for k in range(capi.NFIELDS)]
     s.exchange = None
 
 
