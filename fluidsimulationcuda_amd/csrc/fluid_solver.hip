@@ -327,11 +327,22 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
     // below ~1.5M cells per slab a sweep is bound by launch latency, not bytes: the 256-column
     // windows of the blocked kernel cannot fill 256 CUs and one thread per cell is fastest
     // (measured crossover ~1300^2, profiles/r01_config1_1024.md)
-    const bool small = (long long)(c->own1 - c->own0) * c->n * count < c->tb_min_cells;
+    // fp16 storage rounds once per launch, so there the launch schedule is part of the result: it
+    // must not depend on how the grid is split, how deep the ghost zones are or how solves are
+    // batched.  It is derived from the global problem alone and a short reach triggers an early
+    // exchange instead of a shorter launch.  (fp32 results do not depend on the schedule.)
+    const bool canonical = c->st == fluid::STORAGE_F16;
+    const bool small = (canonical ? (long long)c->n * c->n : (long long)(c->own1 - c->own0) * c->n * count) <
+                       c->tb_min_cells;
     for (int k = 0; k < iters;) {
         const int remaining = iters - k;
-        if (r < 1) {
-            const int depth = std::max(1, std::min(c->halo, remaining + final_reach));
+        auto pick = [&](int room) {
+            if (c->variant != fluid::JACOBI_TB || small) return 1;
+            return (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
+        };
+        const int wantT = canonical ? pick(remaining) : 1;     // slabs with fp16 storage keep halo >= 8 (fluid_create_ex)
+        if (r < wantT) {
+            const int depth = std::max(wantT, std::min(c->halo, remaining + final_reach));
             std::vector<int> ids;
             for (int j = 0; j < count; ++j) {
                 ids.push_back(cur[j]);
@@ -340,10 +351,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
             TRY(need_list(c, ids, depth));
             r = reach_now();
         }
-        const int room = std::min(r, remaining);
-        int T = 1;
-        if (c->variant == fluid::JACOBI_TB && !small)
-            T = (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
+        const int T = canonical ? wantT : pick(std::min(r, remaining));
         int lo, hi;
         rows(c, multi ? std::min(r - T, exchange_cap(c)) : 0, &lo, &hi);
         if (T == 1) {
@@ -712,6 +720,15 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
     // 1024-row slab; shallower on short slabs
     const int want = cfg->halo > 0 ? cfg->halo : std::max(4, std::min(42, base / 8));
     c->halo = P > 1 ? std::max(1, std::min(want, base - 1)) : 1;
+    if (P > 1 && cfg->storage == FLUID_STORAGE_F16) {
+        // fp16 results depend on the launch schedule (one rounding per launch); keeping it identical to the
+        // one-GPU schedule needs ghost zones at least as deep as the longest fused launch
+        if (base - 1 < 8) {
+            delete c;
+            return fail(FLUID_E_INVALID, "fp16 storage needs row slabs of at least 9 rows (N=%d over %d slabs gives %d)", n, P, base);
+        }
+        c->halo = std::max(c->halo, 8);
+    }
     const size_t bytes = c->field_bytes * FLUID_NFIELDS + kControlBytes;
     int rc = FLUID_OK;
     auto bail = [&](int code) { fluid_destroy(c); return code; };
@@ -883,7 +900,7 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
         return FLUID_OK;
     case FLUID_PARAM_HALO:
         if (value < 1) return fail(FLUID_E_INVALID, "HALO must be >= 1");
-        c->halo = c->nranks > 1 ? std::max(1, std::min(value, c->min_slab - 1)) : 1;
+        c->halo = c->nranks > 1 ? std::max(c->st == fluid::STORAGE_F16 ? 8 : 1, std::min(value, c->min_slab - 1)) : 1;
         return FLUID_OK;
     default:
         return fail(FLUID_E_INVALID, "unknown parameter %d", key);

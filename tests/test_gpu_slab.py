@@ -66,14 +66,14 @@ class FakeFabric:
         return cb
 
 
-def run_ranks(n, nranks, halo, fields, body, jacobi=0):
+def run_ranks(n, nranks, halo, fields, body, jacobi=0, storage=0):
     """Run body(solver) on every fake rank; returns the gathered fields."""
     from fluidsimulationcuda_amd.slab import SlabSolver
     fab = FakeFabric(nranks)
     solvers = []
     for r in range(nranks):
         s = SlabSolver.__new__(SlabSolver)
-        _init_fake(s, n, r, nranks, halo, jacobi)
+        _init_fake(s, n, r, nranks, halo, jacobi, storage)
         s.set_exchange(fab.make_callback(r))
         fab.solvers[r] = s
         s.load_global(**fields)
@@ -106,14 +106,14 @@ def run_ranks(n, nranks, halo, fields, body, jacobi=0):
     return out, fab
 
 
-def _init_fake(s, n, rank, nranks, halo, jacobi):
+def _init_fake(s, n, rank, nranks, halo, jacobi, storage=0):
     """SlabSolver.__init__ minus the torch.distributed exchange."""
     import ctypes as C
     import torch
     from fluidsimulationcuda_amd import capi
     from fluidsimulationcuda_amd.solver import FluidSolver
     L = capi.lib()
-    nbytes = L.fluid_arena_bytes(n)
+    nbytes = L.fluid_arena_bytes_ex(n, storage)
     pitch, xoff, ff = C.c_int(), C.c_int(), C.c_size_t()
     capi.check(L.fluid_layout(n, C.byref(pitch), C.byref(xoff), C.byref(ff)))
     s.pitch, s.xoff, s.device = pitch.value, xoff.value, torch.device("cuda", 0)
@@ -122,17 +122,18 @@ def _init_fake(s, n, rank, nranks, halo, jacobi):
     torch.cuda.synchronize()
     FluidSolver.__init__(s, n, rank=rank, nranks=nranks, halo=halo, jacobi=jacobi,
                          stream=s.torch_stream.cuda_stream,
-                         arena_ptr=s.arena.data_ptr(), arena_bytes=nbytes,
+                         arena_ptr=s.arena.data_ptr(), arena_bytes=nbytes, storage=storage,
                          params={capi.PARAM_TB_MIN_CELLS: 0})     # fuse sweeps even on these small slabs
-    s._fb = ff.value * 4
-    s._views = [s.arena[k * s._fb:(k + 1) * s._fb].view(torch.float32).view(n + 2, s.pitch)
-                for k in range(capi.NFIELDS)]
+    esz, dt = (2, torch.float16) if storage else (4, torch.float32)
+    s._fb = ff.value * esz
+    s._views = [s.arena[k * s._fb:(k + 1) * s._fb].view(dt).view(n + 2, s.pitch) for k in range(capi.NFIELDS)]
     s.exchange = None
 
 
-def single(n, fields, body):
+def single(n, fields, body, storage=0):
     import fluidsimulationcuda_amd as F
-    with F.FluidSolver(n) as s:
+    from fluidsimulationcuda_amd import capi
+    with F.FluidSolver(n, storage=storage, params={capi.PARAM_TB_MIN_CELLS: 0}) as s:
         s.upload(**fields)
         body(s)
         return {k: s.download(k) for k in ("u", "v", "dens", "u_prev", "v_prev", "dens_prev")}
@@ -245,3 +246,19 @@ def test_missing_exchange_callback_is_an_error():
         with pytest.raises(capi.FluidError) as e:
             s.step(1)
         assert e.value.code == capi.E_COMM
+
+
+@pytest.mark.parametrize("n,nranks,halo", [(254, 2, 0), (510, 4, 16), (257, 3, 5)])
+def test_fp16_storage_on_slabs_is_bit_identical_to_one_gpu(n, nranks, halo):
+    """Same contract with fp16 fields: the slabs exchange half rows and fuse the
+    same launches per field, so they reproduce the single-context bits."""
+    fields = synthetic(n)
+
+    def body(s):
+        s.step(1, use_sources=True)
+        s.step(1)
+
+    want = single(n, fields, body, storage=1)
+    got, _ = run_ranks(n, nranks, halo, fields, body, jacobi=3, storage=1)
+    for k in ("u", "v", "dens"):
+        assert_bit_equal(got[k], want[k], "fp16 %s, %d slabs" % (k, nranks))
