@@ -58,6 +58,43 @@ __device__ __forceinline__ void st4(half_t* p, const float4& v)
     *reinterpret_cast<half4_t*>(p) = h;
 }
 
+// Buffer-resource forms of ld4/st4 for the fused kernel's steady state: the
+// hardware range check (offset >= num_records: loads return 0, stores are
+// dropped) replaces every `if` around a memory operation, so the loop body has a
+// fixed number of them and hipcc can emit counted s_waitcnt vmcnt(N) instead of
+// draining the queue (vmcnt(0)) once per iteration -- which is what keeps three
+// rows of loads in flight.  kBufOff disables a lane: added to any in-field
+// offset it stays below 2^32 and above num_records (fields are < 2 GiB).
+constexpr unsigned kBufOff = 0x80000000u;
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 buf_ld4(const float*, __amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    const uint4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+__device__ __forceinline__ float4 buf_ld4(const half_t*, __amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    const uint2_t u = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    half4_t h;
+    __builtin_memcpy(&h, &u, 8);
+    return make_float4(keep_f32((float)h.x), keep_f32((float)h.y), keep_f32((float)h.z), keep_f32((float)h.w));
+}
+__device__ __forceinline__ void buf_st4(float*, __amdgpu_buffer_rsrc_t r, unsigned off, const float4& v)
+{
+    uint4_t u;
+    u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, 0);
+}
+__device__ __forceinline__ void buf_st4(half_t*, __amdgpu_buffer_rsrc_t r, unsigned off, const float4& v)
+{
+    half4_t h;
+    h.x = (half_t)keep_f32(v.x); h.y = (half_t)keep_f32(v.y); h.z = (half_t)keep_f32(v.z); h.w = (half_t)keep_f32(v.w);
+    uint2_t u;
+    __builtin_memcpy(&u, &h, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(u, r, off, 0, 0);
+}
+
 // value of lane-1 / lane+1 across the whole 64-wide wave (DPP wave shifts; one
 // VALU op each, no LDS).  Lane 0 / 63 receive `edge`.
 __device__ __forceinline__ float from_lane_below(float v, float edge)
@@ -366,6 +403,10 @@ struct TbArgs {
     const S* xc;          // x   + column offset of this lane
     const S* rc;          // x0  + column offset
     S* oc;                // out + column offset
+    __amdgpu_buffer_rsrc_t bx, br, bo;   // the three fields as range-checked buffers
+    unsigned ld_off;      // byte offset of this lane's float4 in row 0 (kBufOff: lane loads nothing)
+    unsigned st_off;      // same for stores (kBufOff unless the lane owns its columns)
+    unsigned row_bytes;
     size_t P;
     int n, q_lo, q_hi, t_ld, cg, last;
     float alpha, beta;
@@ -504,9 +545,11 @@ __device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T 
     constexpr int UP = PH % 3, ME = (PH + 1) % 3, FR = (PH + 2) % 3;
     W[0][FR] = PX[PH];                                   // stage 0: row t of x (loaded three steps ago)
     Q[0] = PQ[PH];
-    if (t + 3 <= a.t_ld && a.ld_ok) {                    // refill the slot with row t+3: three steps of
-        PX[PH] = ld4(a.xc + (size_t)(t + 3) * a.P);      // arithmetic cover the HBM latency
-        PQ[PH] = ld4(a.rc + (size_t)(t + 3) * a.P);
+    {   // refill the slot with row t+3: three steps of arithmetic cover the HBM latency.  Rows past
+        // the field's end and lanes past its width fall outside the buffer and read as 0.
+        const unsigned off = a.ld_off + (unsigned)(t + 3) * a.row_bytes;
+        PX[PH] = buf_ld4(a.xc, a.bx, off);
+        PQ[PH] = buf_ld4(a.rc, a.br, off);
     }
 #pragma unroll
     for (int s = 1; s <= T; ++s) {
@@ -515,8 +558,16 @@ __device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T 
             float4 G = tb_stencil<DIVMODE>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.beta, a.yd);
             float v1 = 0.f, vn = 0.f;
             if (EDGE) tb_fix_columns(G, a, v1, vn);
-            if (s < T) W[s][FR] = G;
-            else if (q >= a.q_lo && q < a.q_hi) tb_store<EDGE>(G, q, a, v1, vn);
+            if (s < T) {
+                W[s][FR] = G;
+            } else if (!EDGE) {
+                // interior window of an interior strip: one unconditional store; rows outside
+                // [q_lo,q_hi) and the overlap lanes are sent outside the buffer and dropped
+                const bool mine = (q >= a.q_lo) & (q < a.q_hi);
+                buf_st4(a.oc, a.bo, (mine ? a.st_off : kBufOff) + (unsigned)q * a.row_bytes, G);
+            } else if (q >= a.q_lo && q < a.q_hi) {
+                tb_store<EDGE>(G, q, a, v1, vn);
+            }
         } else {
             // ring writes stay unconditional (selected values), so the rings stay in registers
             const bool interior = (q >= 1 && q <= a.n);
@@ -553,10 +604,9 @@ __device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs<S>& a)
     for (int d = 0; d < 3; ++d) {                        // rows t0, t0+1, t0+2 in flight before the first step
         PX[d] = zero4;
         PQ[d] = zero4;
-        if (t0 + d <= a.t_ld && a.ld_ok) {
-            PX[d] = ld4(a.xc + (size_t)(t0 + d) * a.P);
-            PQ[d] = ld4(a.rc + (size_t)(t0 + d) * a.P);
-        }
+        const unsigned off = a.ld_off + (unsigned)(t0 + d) * a.row_bytes;
+        PX[d] = buf_ld4(a.xc, a.bx, off);
+        PQ[d] = buf_ld4(a.rc, a.br, off);
     }
     // whole triples only: up to two surplus steps load nothing (t > t_ld) and store nothing (q >= q_hi)
     for (int t = t0; t <= t1; t += 3) {
@@ -582,7 +632,9 @@ __global__ __launch_bounds__(256, (T <= 4 ? 3 : 2)) void k_jacobi_tb(TbBatch bat
     constexpr int HL = (T + 3) / 4;
     constexpr int VS = 64 - 2 * HL;
     const int lane = threadIdx.x & 63;
-    const int strip = blockIdx.y * 4 + (threadIdx.x >> 6);
+    // the wave index is uniform, but anything derived from threadIdx is divergent to hipcc: readfirstlane
+    // makes the strip bounds (and with them the loop control and the store conditions) scalar
+    const int strip = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     TbArgs<S> a;
     a.yd = yd;
     a.q_lo = row_lo + strip * rb;                        // this wave's output rows [q_lo, q_hi)
@@ -597,6 +649,15 @@ __global__ __launch_bounds__(256, (T <= 4 ? 3 : 2)) void k_jacobi_tb(TbBatch bat
     a.xc = x + cofs;
     a.rc = x0 + cofs;
     a.oc = out + cofs;
+    {
+        const unsigned field_bytes = (unsigned)((size_t)(n + 2) * a.P * sizeof(S));    // < 2 GiB (launch_jacobi_tb)
+        a.bx = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(x), 0, field_bytes, 0x00020000);
+        a.br = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(x0), 0, field_bytes, 0x00020000);
+        a.bo = __builtin_amdgcn_make_buffer_rsrc(out, 0, field_bytes, 0x00020000);
+        a.row_bytes = (unsigned)(a.P * sizeof(S));
+        const unsigned col = (unsigned)((XOFF + 1 + 4 * (ptrdiff_t)k) * (ptrdiff_t)sizeof(S));
+        a.ld_off = a.ld_ok ? col : kBufOff;
+    }
     a.n = n;
     const int kg = n >> 2;                               // ghost column n+1 = component cg of vector kg
     a.cg = n & 3;
@@ -605,6 +666,7 @@ __global__ __launch_bounds__(256, (T <= 4 ? 3 : 2)) void k_jacobi_tb(TbBatch bat
     a.is_lg = (k == -1);
     a.is_rg = (k == kg);
     a.own = (lane >= HL) && (lane < 64 - HL);
+    a.st_off = (a.own && a.ld_ok) ? a.ld_off : kBufOff;
     a.st_int = a.own && k >= 0 && k < nvec;              // stores interior columns
     a.st_rg = a.is_rg && (a.own || k == nvec);           // stores ghost column n+1 (exactly one lane grid-wide)
     a.last = n - (1 + 4 * k);                            // component of column n in this lane (if 0..3)
