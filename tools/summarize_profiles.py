@@ -23,8 +23,8 @@ import sys
 def short(name):
     name = name.replace("void ", "")
     name = name.split("(")[0].replace("fluid::", "")
-    if name.startswith("k_jacobi_tb<"):        # k_jacobi_tb<8, 2> -> k_jacobi_tb<8> (division modes pooled)
-        name = name.split(",")[0] + ">"
+    # k_jacobi_tb<8, 1, float>: the pressure solves (one field per launch); <8, 2, float>: the
+    # batched u/v/density diffusion (three fields per launch) -- kept apart
     return name
 
 
