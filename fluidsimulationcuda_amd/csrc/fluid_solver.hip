@@ -337,7 +337,9 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
     for (int k = 0; k < iters;) {
         const int remaining = iters - k;
         auto pick = [&](int room) {
-            if (c->variant != fluid::JACOBI_TB || small) return 1;
+            // the fused kernel addresses a field through 32-bit buffer offsets: fields of 2 GiB and more
+            // (beyond ~23000^2 in fp32) take single-sweep launches
+            if (c->variant != fluid::JACOBI_TB || small || c->field_bytes >= 0x7F000000ull) return 1;
             return (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
         };
         const int wantT = canonical ? pick(remaining) : 1;     // slabs with fp16 storage keep halo >= 8 (fluid_create_ex)
