@@ -26,6 +26,7 @@ struct TbBatch {
     float alpha[3], beta[3];     // beta: divisor, or its exact reciprocal in division mode 1
     double yd[3];                // RN64(1/beta) for division mode 2
     int b[3];
+    int x_zero[3];               // first guess known to be all +0: never read
     int count;
 };
 
@@ -39,7 +40,7 @@ void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, doub
 void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u, const void* v, int pitch, int n,
                    int row_lo, int row_hi, float dt0, int b);
 void launch_divergence(hipStream_t s, int st, const void* u, const void* v, void* p, void* div, int pitch, int n,
-                       int row_lo, int row_hi, float h);
+                       int row_lo, int row_hi, float h, int write_p);
 void launch_subtract_gradient(hipStream_t s, int st, void* u, void* v, const void* p, int pitch, int n, int row_lo,
                               int row_hi, float h);
 void launch_absmax2(hipStream_t s, int st, const void* u, const void* v, int pitch, int n, int row_lo, int row_hi,

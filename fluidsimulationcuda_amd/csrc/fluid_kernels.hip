@@ -207,6 +207,24 @@ __global__ __launch_bounds__(256) void k_add_source(S* __restrict__ x, const S* 
     }
 }
 
+// add_source when the source field is known to be all +0: x += inc with inc = dt*(+0)
+// formed on the host (so x = -0 still becomes +0 for dt >= 0, exactly as x + dt*0 does).
+template <typename S>
+__global__ __launch_bounds__(256) void k_add_zero_source(S* __restrict__ x, int pitch, int row_lo, int row_hi, float inc)
+{
+    const int nvec = pitch >> 2;
+    const size_t total = (size_t)(row_hi - row_lo) * nvec;
+    S* xv = x + (size_t)row_lo * pitch;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        float4 a = ld4(xv + 4 * t);
+        a.x = a.x + inc;
+        a.y = a.y + inc;
+        a.z = a.z + inc;
+        a.w = a.w + inc;
+        st4(xv + 4 * t, a);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // a4  Jacobi sweep, three variants.  All compute, for interior rows
 // [row_lo,row_hi) and columns 1..n,
@@ -651,7 +669,9 @@ __global__ __launch_bounds__(256, (T <= 4 ? 3 : 2)) void k_jacobi_tb(TbBatch bat
     a.oc = out + cofs;
     {
         const unsigned field_bytes = (unsigned)((size_t)(n + 2) * a.P * sizeof(S));    // < 2 GiB (launch_jacobi_tb)
-        a.bx = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(x), 0, field_bytes, 0x00020000);
+        // a first guess known to be all +0 (sources after step 0, the pressure) is never read: an
+        // empty descriptor makes every load of it return 0
+        a.bx = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(x), 0, batch.x_zero[blockIdx.z] ? 0u : field_bytes, 0x00020000);
         a.br = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(x0), 0, field_bytes, 0x00020000);
         a.bo = __builtin_amdgcn_make_buffer_rsrc(out, 0, field_bytes, 0x00020000);
         a.row_bytes = (unsigned)(a.P * sizeof(S));
@@ -728,7 +748,7 @@ __global__ __launch_bounds__(256) void k_advect(S* __restrict__ d, const S* __re
 template <typename S>
 __global__ __launch_bounds__(256) void k_divergence(const S* __restrict__ u, const S* __restrict__ v, S* __restrict__ p,
                                                     S* __restrict__ div, int pitch, int n, int row_lo, int row_hi,
-                                                    float h)
+                                                    float h, int write_p)
 {
     const int j = 1 + blockIdx.x * 256 + threadIdx.x;
     const int i = row_lo + blockIdx.y;
@@ -742,8 +762,10 @@ __global__ __launch_bounds__(256) void k_divergence(const S* __restrict__ u, con
     const float val = scale * g;
     st1(div + c, val);
     emit_ghosts(div, P, n, 0, j, i, val);
-    st1(p + c, 0.0f);
-    emit_ghosts(p, P, n, 0, j, i, 0.0f);
+    if (write_p) {          // the solver usually just marks p as "all zero" instead
+        st1(p + c, 0.0f);
+        emit_ghosts(p, P, n, 0, j, i, 0.0f);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -839,10 +861,16 @@ void launch_set_bnd(hipStream_t s, int st, void* f, int pitch, int n, int b)
     FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_set_bnd<S>, dim3(cdiv(n, 256)), dim3(256), 0, s, (S*)f, pitch, n, b));
 }
 
+// src == nullptr: the source is known to be all +0 (dt is then the pre-multiplied increment dt*0)
 void launch_add_source(hipStream_t s, int st, void* x, const void* src, int pitch, int row_lo, int row_hi, float dt)
 {
     const size_t total = (size_t)(row_hi - row_lo) * (pitch >> 2);
     const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (!src) {
+        FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_add_zero_source<S>, dim3(blocks ? blocks : 1), dim3(256), 0, s, (S*)x,
+                                                pitch, row_lo, row_hi, dt));
+        return;
+    }
     FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_add_source<S>, dim3(blocks ? blocks : 1), dim3(256), 0, s, (S*)x,
                                             (const S*)src, pitch, row_lo, row_hi, dt));
 }
@@ -912,11 +940,12 @@ void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u
 }
 
 void launch_divergence(hipStream_t s, int st, const void* u, const void* v, void* p, void* div, int pitch, int n,
-                       int row_lo, int row_hi, float h)
+                       int row_lo, int row_hi, float h, int write_p)
 {
     if (row_hi <= row_lo) return;
     FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_divergence<S>, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s,
-                                            (const S*)u, (const S*)v, (S*)p, (S*)div, pitch, n, row_lo, row_hi, h));
+                                            (const S*)u, (const S*)v, (S*)p, (S*)div, pitch, n, row_lo, row_hi, h,
+                                            write_p));
 }
 
 void launch_subtract_gradient(hipStream_t s, int st, void* u, void* v, const void* p, int pitch, int n, int row_lo,

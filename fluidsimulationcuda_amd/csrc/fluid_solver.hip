@@ -74,6 +74,7 @@ struct fluid_ctx {
     // slab decomposition
     int rank = 0, nranks = 1, own0 = 1, own1 = 1, min_slab = 0, halo = 1;
     int reach[FLUID_NFIELDS] = {};            // see "row-slab bookkeeping" below
+    bool zero[FLUID_NFIELDS] = {};            // field is all +0 by definition; its memory is NOT (yet) zeroed
     fluid_exchange_fn xchg = nullptr;
     void* xchg_user = nullptr;
     // timing
@@ -258,6 +259,33 @@ void rows(const fluid_ctx* c, int reach, int* lo, int* hi)
     *hi = std::min(c->n + 1, c->own1 + reach);
 }
 
+// ---- fields that are zero by definition ---------------------------------------------
+// The sources of every step after the first and the pressure's first guess are
+// all +0.  Writing those zeros and reading them back is pure traffic, so such a
+// field is only MARKED zero; the three consumers that matter take the mark
+// (add_source adds the constant dt*0, the fused Jacobi kernel reads nothing, the
+// divergence kernel skips its p stores) and everything else materialises the
+// zeros first.
+int materialize(fluid_ctx* c, int f)
+{
+    if (!c->zero[f]) return FLUID_OK;
+    HIP_TRY(hipMemsetAsync(c->f[f], 0, c->field_bytes, c->stream));
+    c->zero[f] = false;
+    return FLUID_OK;
+}
+
+int materialize(fluid_ctx* c, std::initializer_list<int> fs)
+{
+    for (int f : fs) TRY(materialize(c, f));
+    return FLUID_OK;
+}
+
+void mark_zero(fluid_ctx* c, int f)
+{
+    c->zero[f] = true;
+    c->reach[f] = kEverywhere;
+}
+
 // ---- operators -------------------------------------------------------------------
 int op_add_source(fluid_ctx* c, int x, int s, float dt)
 {
@@ -267,7 +295,14 @@ int op_add_source(fluid_ctx* c, int x, int s, float dt)
     rows(c, reach, &lo, &hi);
     if (lo == 1) lo = 0;                     // wall rows are cells like any other here (FluidSequential.c:78-82)
     if (hi == c->n + 1) hi = c->n + 2;
-    TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->st, c->f[x], c->f[s], c->pitch, lo, hi, dt));
+    TRY(materialize(c, x));
+    if (c->zero[s]) {
+        volatile float z = 0.0f;
+        const float inc = dt * z;          // the reference's dt * s[i] with s[i] = +0 (sign and NaN rules included)
+        TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->st, c->f[x], nullptr, c->pitch, lo, hi, inc));
+    } else {
+        TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->st, c->f[x], c->f[s], c->pitch, lo, hi, dt));
+    }
     wrote(c, x, reach);
     return FLUID_OK;
 }
@@ -303,6 +338,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 return fail(FLUID_E_INVALID, "diffuse: the solves of a batch must not share fields");
     }
     if (iters == 0) return FLUID_OK;
+    for (int k = 0; k < count; ++k) TRY(materialize(c, sv[k].x0));
     hipEvent_t stop;
     TRY(timing_begin(c, FLUID_TIME_DIFFUSION, &stop));
     const bool multi = c->nranks > 1;
@@ -358,6 +394,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         rows(c, multi ? std::min(r - T, exchange_cap(c)) : 0, &lo, &hi);
         if (T == 1) {
             const int v = c->variant == fluid::JACOBI_TB ? (small ? fluid::JACOBI_NAIVE : fluid::JACOBI_STREAM) : c->variant;
+            for (int j = 0; j < count; ++j) TRY(materialize(c, cur[j]));      // single-sweep kernels read x
             for (int j = 0; j < count; ++j)
                 fluid::launch_jacobi(c->stream, c->st, v, c->f[cur[j]], c->f[sv[j].x0], c->f[nxt[j]], c->pitch, c->n, lo, hi,
                                      sv[j].alpha, sv[j].beta, sv[j].b);
@@ -375,6 +412,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                     bt.beta[m] = div_arg[j];
                     bt.yd[m] = yd[j];
                     bt.b[m] = sv[j].b;
+                    bt.x_zero[m] = c->zero[cur[j]] ? 1 : 0;
                     ++m;
                 }
                 bt.count = m;
@@ -396,6 +434,8 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         }
         r = multi ? std::min(r - T, exchange_cap(c)) : kEverywhere;
         for (int j = 0; j < count; ++j) {
+            c->zero[cur[j]] = false;       // from now on this buffer is just the other half of the ping-pong
+            c->zero[nxt[j]] = false;
             wrote(c, nxt[j], r);
             std::swap(cur[j], nxt[j]);
         }
@@ -428,6 +468,7 @@ int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int 
 int vmax_begin(fluid_ctx* c, int u, int v)
 {
     if (c->nranks == 1) return FLUID_OK;
+    TRY(materialize(c, {u, v}));
     HIP_TRY(hipMemsetAsync(c->d_scalar, 0, sizeof(unsigned), c->stream));
     fluid::launch_absmax2(c->stream, c->st, c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, c->d_scalar);
     TRY(exchange(c, FLUID_XCHG_MAX_BEGIN, {}, 0));       // in-place MAX over ranks on the device scalar
@@ -462,6 +503,8 @@ int op_advect(fluid_ctx* c, int b, int d, int d0, int u, int v, float dt)
 {
     if (d == d0 || d == u || d == v) return fail(FLUID_E_INVALID, "advect: output must not alias an input");
     const float dt0 = dt * (float)c->n;
+    TRY(materialize(c, {d0, u, v}));
+    c->zero[d] = false;
     TIMED(c, FLUID_TIME_ADVECTION,
           fluid::launch_advect(c->stream, c->st, c->f[d], c->f[d0], c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, dt0, b));
     wrote(c, d, 0);
@@ -477,20 +520,20 @@ int op_divergence(fluid_ctx* c, int u, int v, int p, int div, int want = 0)
         return fail(FLUID_E_INVALID, "divergence: outputs must not alias inputs");
     const float h = 1.0f / (float)c->n;
     int reach = 0;
+    TRY(materialize(c, {u, v}));
     if (c->nranks > 1) {
         reach = std::max(0, std::min(want, exchange_cap(c) - 1));
         TRY(need(c, {u, v}, reach + 1));
-        // p = 0 on every row the solve may read: one row further out than the divergence
-        const int z0 = std::max(0, c->own0 - reach - 1), z1 = std::min(c->w, c->own1 + reach + 1);
-        HIP_TRY(hipMemsetAsync(c->row(p, z0), 0, (size_t)(z1 - z0) * c->pitch * c->esz, c->stream));
     }
     int lo, hi;
     rows(c, reach, &lo, &hi);
-    // ghost rows/columns of p and div are written by the fused boundary of the edge rows
+    // p = 0 everywhere (FluidSequential.c:153 + set_bnd(0,p)): marked, not written
     TIMED(c, FLUID_TIME_DIVERGENCE,
-          fluid::launch_divergence(c->stream, c->st, c->f[u], c->f[v], c->f[p], c->f[div], c->pitch, c->n, lo, hi, h));
+          fluid::launch_divergence(c->stream, c->st, c->f[u], c->f[v], c->f[p], c->f[div], c->pitch, c->n, lo, hi, h,
+                                   /*write_p=*/0));
+    c->zero[div] = false;
     wrote(c, div, reach);
-    wrote(c, p, reach + 1);
+    mark_zero(c, p);
     return FLUID_OK;
 }
 
@@ -498,6 +541,7 @@ int op_subtract_gradient(fluid_ctx* c, int u, int v, int p)
 {
     if (p == u || p == v || u == v) return fail(FLUID_E_INVALID, "subtract_gradient: fields must be distinct");
     const float h = 1.0f / (float)c->n;
+    TRY(materialize(c, {u, v, p}));
     TRY(need(c, {p}, 1));
     TIMED(c, FLUID_TIME_PROJECTION,
           fluid::launch_subtract_gradient(c->stream, c->st, c->f[u], c->f[v], c->f[p], c->pitch, c->n, c->own0, c->own1, h));
@@ -607,10 +651,8 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
 
 int zero_sources(fluid_ctx* c)
 {
-    for (int id : {FLUID_U_PREV, FLUID_V_PREV, FLUID_DENS_PREV}) {
-        HIP_TRY(hipMemsetAsync(c->f[id], 0, c->field_bytes, c->stream));
-        wrote(c, id, kEverywhere);
-    }
+    // the reference's zeroing loop (FluidSequential.c:298-302): marked, see "fields that are zero by definition"
+    for (int id : {FLUID_U_PREV, FLUID_V_PREV, FLUID_DENS_PREV}) mark_zero(c, id);
     return FLUID_OK;
 }
 
@@ -618,6 +660,7 @@ int copy_rows(fluid_ctx* c, int field, float* host, const float* chost, int row_
 {
     if (row_lo < 0 || row_hi > c->w || row_lo > row_hi) return fail(FLUID_E_INVALID, "bad row range");
     if (row_lo == row_hi) return FLUID_OK;
+    TRY(materialize(c, field));
     char* dev = static_cast<char*>(c->row(field, row_lo)) + (size_t)XOFF * c->esz;
     const size_t rows = (size_t)(row_hi - row_lo), w = (size_t)c->w;
     const size_t dp = (size_t)c->pitch * c->esz;
@@ -818,6 +861,7 @@ int fluid_field_ptr(fluid_ctx* c, int field, void** dev_ptr)
     TRY(check_ctx(c));
     TRY(check_fields(c, {field}));
     if (!dev_ptr) return fail(FLUID_E_INVALID, "null pointer");
+    TRY(materialize(c, field));            // whoever asks for the address may read the memory
     *dev_ptr = c->f[field];
     return FLUID_OK;
 }
@@ -864,6 +908,7 @@ int fluid_fill(fluid_ctx* c, int field, float value)
     TRY(check_fields(c, {field}));
     if (value == 0.0f && !std::signbit(value)) {
         HIP_TRY(hipMemsetAsync(c->f[field], 0, c->field_bytes, c->stream));
+        c->zero[field] = false;
         wrote(c, field, kEverywhere);
         return FLUID_OK;
     }
@@ -955,6 +1000,7 @@ int fluid_op_set_bnd(fluid_ctx* c, int b, int x)
     TRY(check_fields(c, {x}));
     if (b < 0 || b > 2) return fail(FLUID_E_INVALID, "b must be 0, 1 or 2");
     if (c->nranks != 1) return fail(FLUID_E_INVALID, "fluid_op_set_bnd is a whole-grid operator (1 GPU)");
+    TRY(materialize(c, x));
     fluid::launch_set_bnd(c->stream, c->st, c->f[x], c->pitch, c->n, b);
     HIP_TRY(hipGetLastError());
     return FLUID_OK;
@@ -976,6 +1022,8 @@ int fluid_op_jacobi_sweep(fluid_ctx* c, int b, int x, int x0, int out, float alp
     TRY(check_fields(c, {x, x0, out}));
     if (b < 0 || b > 2) return fail(FLUID_E_INVALID, "b must be 0, 1 or 2");
     if (out == x || out == x0) return fail(FLUID_E_INVALID, "jacobi_sweep: out must not alias an input");
+    TRY(materialize(c, {x, x0}));
+    c->zero[out] = false;
     TRY(need(c, {x}, 1));
     const int v1 = c->variant == fluid::JACOBI_TB ? fluid::JACOBI_STREAM : c->variant;   // one sweep: nothing to block
     fluid::launch_jacobi(c->stream, c->st, v1, c->f[x], c->f[x0], c->f[out], c->pitch, c->n, c->own0, c->own1, alpha, beta, b);
@@ -1028,6 +1076,7 @@ int fluid_residual(fluid_ctx* c, int x, int x0, float alpha, float beta, float* 
     TRY(check_ctx(c));
     TRY(check_fields(c, {x, x0}));
     if (!out) return fail(FLUID_E_INVALID, "null pointer");
+    TRY(materialize(c, {x, x0}));
     TRY(need(c, {x}, 1));
     HIP_TRY(hipMemsetAsync(c->d_scalar, 0, sizeof(unsigned), c->stream));
     fluid::launch_residual(c->stream, c->st, c->f[x], c->f[x0], c->pitch, c->n, c->own0, c->own1, alpha, beta, c->d_scalar);
@@ -1040,6 +1089,7 @@ int fluid_absmax_velocity(fluid_ctx* c, int u, int v, float* out)
     TRY(check_ctx(c));
     TRY(check_fields(c, {u, v}));
     if (!out) return fail(FLUID_E_INVALID, "null pointer");
+    TRY(materialize(c, {u, v}));
     HIP_TRY(hipMemsetAsync(c->d_scalar, 0, sizeof(unsigned), c->stream));
     fluid::launch_absmax2(c->stream, c->st, c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, c->d_scalar);
     TRY(reduce_to_host(c, out));

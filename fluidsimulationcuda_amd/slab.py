@@ -65,12 +65,14 @@ class TorchExchange:
     def _dispatch(self, kind, ids, depth, scalar):
         if kind == capi.XCHG_MAX_BEGIN:
             self.calls[capi.XCHG_MAX] += 1
+            self._reduced_on_device = False
             if not self.staged and self.scalar is not None:
-                # non-negative floats: MAX on the device word, in place, on the solver's stream
-                dist.all_reduce(self.scalar, op=dist.ReduceOp.MAX, group=self.group)
-                self._reduced_on_device = True
-            else:
-                self._reduced_on_device = False
+                try:
+                    # non-negative floats: MAX on the device word, in place, on the solver's stream
+                    dist.all_reduce(self.scalar, op=dist.ReduceOp.MAX, group=self.group)
+                    self._reduced_on_device = True
+                except RuntimeError:
+                    self.scalar = None       # this transport cannot do it: reduce on the host at END from now on
             return None
         if kind == capi.XCHG_MAX_END:
             return scalar if self._reduced_on_device else self.maximum(scalar)
