@@ -35,7 +35,7 @@ void launch_add_source(hipStream_t s, int st, void* x, const void* src, int pitc
 void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void* x0, void* out, int pitch, int n,
                    int row_lo, int row_hi, float alpha, float beta, int b);
 void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, const TbBatch& batch, int pitch, int n, int row_lo,
-                      int row_hi, int rb);
+                      int row_hi, int rb, int rb_edge);
 void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, double yd, unsigned long long* bad);
 void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u, const void* v, int pitch, int n,
                    int row_lo, int row_hi, float dt0, int b);

@@ -95,6 +95,18 @@ __device__ __forceinline__ void buf_st4(half_t*, __amdgpu_buffer_rsrc_t r, unsig
     __builtin_amdgcn_raw_buffer_store_b64(u, r, off, 0, 0);
 }
 
+__device__ __forceinline__ void buf_st1(float*, __amdgpu_buffer_rsrc_t r, unsigned off, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0);
+}
+__device__ __forceinline__ void buf_st1(half_t*, __amdgpu_buffer_rsrc_t r, unsigned off, float v)
+{
+    const half_t h = (half_t)keep_f32(v);
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    __builtin_amdgcn_raw_buffer_store_b16(u, r, off, 0, 0);
+}
+
 // value of lane-1 / lane+1 across the whole 64-wide wave (DPP wave shifts; one
 // VALU op each, no LDS).  Lane 0 / 63 receive `edge`.
 __device__ __forceinline__ float from_lane_below(float v, float edge)
@@ -423,14 +435,14 @@ struct TbArgs {
     S* oc;                // out + column offset
     __amdgpu_buffer_rsrc_t bx, br, bo;   // the three fields as range-checked buffers
     unsigned ld_off;      // byte offset of this lane's float4 in row 0 (kBufOff: lane loads nothing)
-    unsigned st_off;      // same for stores (kBufOff unless the lane owns its columns)
+    unsigned st_off;      // same for the float4 store (kBufOff unless the lane owns interior or ghost columns)
     unsigned row_bytes;
     size_t P;
     int n, q_lo, q_hi, t_ld, cg, last;
     float alpha, beta;
     double yd;            // DIVMODE 2: 1/beta rounded to double
     unsigned sx, sy;      // sign masks: flip across vertical / horizontal walls
-    bool ld_ok, own, st_int, st_rg, is_lg, is_rg, left_edge, right_edge;
+    bool ld_ok, own, st_int, st_rg_lane, is_lg, is_rg, left_edge, right_edge;
 };
 
 __device__ __forceinline__ float fxor(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) ^ m); }
@@ -495,48 +507,32 @@ __device__ __forceinline__ void tb_fix_columns(float4& G, const TbArgs<S>& a, fl
     }
 }
 
-// final stage: store row q, its ghost columns, and ghost rows / corners
-template <bool EDGE, typename S>
-__device__ __forceinline__ void tb_store(const float4& G, int q, const TbArgs<S>& a, float v1, float vn)
+// final stage: store row q, its ghost columns, and ghost rows / corners -- WITHOUT branches.
+// Every lane that holds anything to be stored writes its whole float4 through the range-checked
+// buffer: the ragged last vector and the two ghost-column lanes spill their surplus components
+// into pad floats (never read as data), so edge windows issue the same single store per step as
+// interior ones; wall strips add the two ghost rows, enabled by a select on the offset.  A fixed
+// number of memory operations per step is what lets hipcc count them (see buf_ld4).
+template <bool EDGE, bool WALL, typename S>
+__device__ __forceinline__ void tb_store(const float4& G, int q, bool mine, const TbArgs<S>& a, float v1, float vn)
 {
-    const bool top = (q == 1), bot = (q == a.n);
-    const float4 g4 = fxor4(G, a.sy);
-    if (!EDGE) {
-        if (a.own) {
-            st4(a.oc + (size_t)q * a.P, G);
-            if (top) st4(a.oc, g4);
-            if (bot) st4(a.oc + (size_t)(a.n + 1) * a.P, g4);
-        }
-        return;
-    }
-    if (a.st_int) {
-#pragma unroll
-        for (int side = 0; side < 3; ++side) {
-            if (side == 1 && !top) continue;
-            if (side == 2 && !bot) continue;
-            S* o = a.oc + (side == 0 ? (size_t)q : side == 1 ? (size_t)0 : (size_t)(a.n + 1)) * a.P;
-            const float4 val = side == 0 ? G : g4;
-            if (a.last >= 3) {
-                st4(o, val);
-            } else {
-                st1(o, val.x);
-                if (a.last >= 1) st1(o + 1, val.y);
-                if (a.last >= 2) st1(o + 2, val.z);
+    auto on = [](bool c, unsigned off) { return c ? off : kBufOff; };
+    buf_st4(a.oc, a.bo, on(mine, a.st_off) + (unsigned)q * a.row_bytes, G);
+    if (WALL) {
+        float4 g4 = fxor4(G, a.sy);                      // ghost row = flipped wall row ...
+        if (EDGE) {                                      // ... except its two corner cells
+            const float cl = 0.5f * (fxor(v1, a.sy) + fxor(v1, a.sx));
+            const float cr = 0.5f * (fxor(vn, a.sy) + fxor(vn, a.sx));
+            if (a.is_lg) g4.w = cl;
+            if (a.st_rg_lane) {
+                if (a.cg == 0) g4.x = cr;
+                else if (a.cg == 1) g4.y = cr;
+                else if (a.cg == 2) g4.z = cr;
+                else g4.w = cr;
             }
         }
-    }
-    if (a.is_lg) {                       // ghost column 0 (+ corners): only window 0 has k == -1
-        st1(a.oc + (size_t)q * a.P + 3, G.w);
-        const float corner = 0.5f * (fxor(v1, a.sy) + fxor(v1, a.sx));
-        if (top) st1(a.oc + 3, corner);
-        if (bot) st1(a.oc + (size_t)(a.n + 1) * a.P + 3, corner);
-    }
-    if (a.st_rg) {                       // ghost column n+1 (+ corners)
-        const float gv = a.cg == 0 ? G.x : a.cg == 1 ? G.y : a.cg == 2 ? G.z : G.w;
-        st1(a.oc + (size_t)q * a.P + a.cg, gv);
-        const float corner = 0.5f * (fxor(vn, a.sy) + fxor(vn, a.sx));
-        if (top) st1(a.oc + a.cg, corner);
-        if (bot) st1(a.oc + (size_t)(a.n + 1) * a.P + a.cg, corner);
+        buf_st4(a.oc, a.bo, on(mine & (q == 1), a.st_off), g4);                                        // row 0
+        buf_st4(a.oc, a.bo, on(mine & (q == a.n), a.st_off) + (unsigned)(a.n + 1) * a.row_bytes, g4);  // row n+1
     }
 }
 
@@ -576,16 +572,8 @@ __device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T 
             float4 G = tb_stencil<DIVMODE>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.beta, a.yd);
             float v1 = 0.f, vn = 0.f;
             if (EDGE) tb_fix_columns(G, a, v1, vn);
-            if (s < T) {
-                W[s][FR] = G;
-            } else if (!EDGE) {
-                // interior window of an interior strip: one unconditional store; rows outside
-                // [q_lo,q_hi) and the overlap lanes are sent outside the buffer and dropped
-                const bool mine = (q >= a.q_lo) & (q < a.q_hi);
-                buf_st4(a.oc, a.bo, (mine ? a.st_off : kBufOff) + (unsigned)q * a.row_bytes, G);
-            } else if (q >= a.q_lo && q < a.q_hi) {
-                tb_store<EDGE>(G, q, a, v1, vn);
-            }
+            if (s < T) W[s][FR] = G;
+            else tb_store<EDGE, false>(G, q, (q >= a.q_lo) & (q < a.q_hi), a, v1, vn);
         } else {
             // ring writes stay unconditional (selected values), so the rings stay in registers
             const bool interior = (q >= 1 && q <= a.n);
@@ -601,8 +589,8 @@ __device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T 
                                        bot_ghost ? flipped_me.z : G.z, bot_ghost ? flipped_me.w : G.w);
                 W[s][ME] = make_float4(top_ghost ? flipped_g.x : me.x, top_ghost ? flipped_g.y : me.y,
                                        top_ghost ? flipped_g.z : me.z, top_ghost ? flipped_g.w : me.w);
-            } else if (interior && q >= a.q_lo && q < a.q_hi) {
-                tb_store<EDGE>(G, q, a, v1, vn);
+            } else {
+                tb_store<EDGE, true>(G, q, interior & (q >= a.q_lo) & (q < a.q_hi), a, v1, vn);
             }
         }
     }
@@ -639,7 +627,7 @@ __device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs<S>& a)
 // diffusion): more waves per launch, hence taller strips and less pipeline-fill redundancy.
 template <int T, int DIVMODE, typename S>
 __global__ __launch_bounds__(256, (T <= 4 ? 3 : 2)) void k_jacobi_tb(TbBatch batch, int pitch, int n, int row_lo, int row_hi,
-                                                                    int rb)
+                                                                    int rb, int rb_edge)
 {
     const S* __restrict__ x = static_cast<const S*>(batch.x[blockIdx.z]);
     const S* __restrict__ x0 = static_cast<const S*>(batch.x0[blockIdx.z]);
@@ -653,12 +641,17 @@ __global__ __launch_bounds__(256, (T <= 4 ? 3 : 2)) void k_jacobi_tb(TbBatch bat
     // the wave index is uniform, but anything derived from threadIdx is divergent to hipcc: readfirstlane
     // makes the strip bounds (and with them the loop control and the store conditions) scalar
     const int strip = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int win = blockIdx.x;
+    // the two windows that carry the ghost columns do extra work per stage; they get shorter strips
+    // (rb_edge < rb, more of them) so that they do not finish long after everybody else
+    const int kg0 = n >> 2;
+    const bool edge_win = (win == 0) || ((kg0 >= win * VS - HL) && (kg0 < win * VS - HL + 64));
+    const int rbw = edge_win ? rb_edge : rb;
     TbArgs<S> a;
     a.yd = yd;
-    a.q_lo = row_lo + strip * rb;                        // this wave's output rows [q_lo, q_hi)
+    a.q_lo = row_lo + strip * rbw;                       // this wave's output rows [q_lo, q_hi)
     if (a.q_lo >= row_hi) return;                        // wave-uniform
-    a.q_hi = min(a.q_lo + rb, row_hi);
-    const int win = blockIdx.x;
+    a.q_hi = min(a.q_lo + rbw, row_hi);
     const int k = win * VS - HL + lane;                  // float4 index: columns 1+4k .. 4+4k
     const int nvec = (n + 3) >> 2;
     a.ld_ok = k <= (pitch >> 2) - 17;                    // k >= -HL >= -16 always
@@ -686,10 +679,12 @@ __global__ __launch_bounds__(256, (T <= 4 ? 3 : 2)) void k_jacobi_tb(TbBatch bat
     a.is_lg = (k == -1);
     a.is_rg = (k == kg);
     a.own = (lane >= HL) && (lane < 64 - HL);
-    a.st_off = (a.own && a.ld_ok) ? a.ld_off : kBufOff;
     a.st_int = a.own && k >= 0 && k < nvec;              // stores interior columns
-    a.st_rg = a.is_rg && (a.own || k == nvec);           // stores ghost column n+1 (exactly one lane grid-wide)
+    a.st_rg_lane = a.is_rg && (a.own || k == nvec);      // stores ghost column n+1 (exactly one lane grid-wide)
     a.last = n - (1 + 4 * k);                            // component of column n in this lane (if 0..3)
+    // lanes that store: owners of interior columns (the ragged last vector included), the lane whose
+    // .w is ghost column 0 and the lane holding ghost column n+1; surplus components go to pads
+    a.st_off = (a.ld_ok && (a.st_int || a.is_lg || a.st_rg_lane)) ? a.ld_off : kBufOff;
     a.sx = (b == 1) ? 0x80000000u : 0u;
     a.sy = (b == 2) ? 0x80000000u : 0u;
     a.alpha = alpha;
@@ -904,15 +899,17 @@ void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void
 // T in {8,4,2}; batch.count solves per launch.  divmode 0: beta; 1: beta = exact reciprocal;
 // 2: beta unused, yd = RN64(1/beta).
 void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, const TbBatch& batch, int pitch, int n, int row_lo,
-                      int row_hi, int rb)
+                      int row_hi, int rb, int rb_edge)
 {
     const int rows = row_hi - row_lo;
     if (rows <= 0 || batch.count <= 0) return;
     const int HL = (T + 3) / 4, VS = 64 - 2 * HL;
     const unsigned nvec = (n + 3) / 4;
-    const dim3 grid(cdiv(nvec, VS), cdiv(cdiv(rows, rb), 4), batch.count), block(256);
+    rb_edge = rb_edge < 1 ? rb : (rb_edge > rb ? rb : rb_edge);
+    // grid.y covers the edge windows' (larger) strip count; interior windows leave the surplus blocks at once
+    const dim3 grid(cdiv(nvec, VS), cdiv(cdiv(rows, rb_edge), 4), batch.count), block(256);
 #define FLUID_TB1(TT, DD) \
-    FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_jacobi_tb<TT, DD, S>), grid, block, 0, s, batch, pitch, n, row_lo, row_hi, rb))
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_jacobi_tb<TT, DD, S>), grid, block, 0, s, batch, pitch, n, row_lo, row_hi, rb, rb_edge))
 #define FLUID_TB(TT)                     \
     if (divmode == 2) FLUID_TB1(TT, 2);  \
     else if (divmode == 1) FLUID_TB1(TT, 1); \

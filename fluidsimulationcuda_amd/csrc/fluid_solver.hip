@@ -69,6 +69,7 @@ struct fluid_ctx {
     int variant = fluid::JACOBI_TB;
     int tb_max_t = 8, tb_rows = 0, num_cu = 256;   // temporal blocking: sweeps/launch cap, rows/strip (0 = auto)
     long long tb_min_cells = 1500000;              // smaller slabs use single-sweep launches
+    int tb_edge_pct = 40;                          // strip height of the two edge windows, % of the others'
     bool fast_div = true;                          // allow division modes 1/2 (each beta proven on the device first)
     std::unordered_map<unsigned, int> div_mode;    // beta bits -> proven division mode
     // slab decomposition
@@ -417,18 +418,30 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 }
                 bt.count = m;
                 int rb = c->tb_rows;
+                const int edge_pct = c->tb_edge_pct > 0 ? c->tb_edge_pct : 100;
+                auto edge_rows = [&](int r) { return std::max(2 * T, r * edge_pct / 100); };
                 if (rb <= 0) {
-                    // auto (tools/tb_sweep.py on MI355X, 4096^2 and 8192^2): the register-heavy T=8 kernel
-                    // holds 2 waves per SIMD and likes one full round of them; T<=4 holds 3 and peaks
-                    // near 2.8.  Longer strips amortise the 2T-row pipeline fill, shorter ones feed more
-                    // SIMDs; a batch of solves multiplies the waves, so its strips can be that much taller.
+                    // auto (tools/tb_sweep.py on MI355X): the kernel is latency-bound per wave, so it wants
+                    // every block resident at once -- 2 blocks per CU at T=8 (~200 VGPRs), 3 below -- and
+                    // then the tallest strips that still allow (each strip pays 2T rows of pipeline fill).
+                    // Smallest strip height whose non-empty blocks fit 92 % of one round; grids too large for
+                    // one round stop at 80 rows (160 for a batch), past which more strips win again.
                     const int HL = (T + 3) / 4, VS = 64 - 2 * HL;
                     const long long windows = ((c->n + 3) / 4 + VS - 1) / VS;
-                    const long long want = (long long)c->num_cu * 4 * (T >= 8 ? 19 : 28) / 10;
-                    rb = (int)(((long long)(hi - lo) * windows * m + want - 1) / want);
-                    rb = std::max(2 * T, std::min(rb, T >= 8 ? 160 : 192));
+                    const long long room = (long long)c->num_cu * (T >= 8 ? 2 : 3) * 92 / 100;
+                    const long long rows_n = hi - lo;
+                    auto blocks = [&](int r) {
+                        const long long si = (rows_n + r - 1) / r, se = (rows_n + edge_rows(r) - 1) / edge_rows(r);
+                        const long long inner = windows > 2 ? windows - 2 : 0, outer = windows - inner;
+                        return (inner * ((si + 3) / 4) + outer * ((se + 3) / 4)) * m;
+                    };
+                    const int cap = (T >= 8 ? 80 : 96) * (m > 1 ? 2 : 1);
+                    rb = 2 * T;
+                    while (rb < cap && blocks(rb) > room) rb += 2;
                 }
-                fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], bt, c->pitch, c->n, lo, hi, rb);
+                // edge windows (ghost columns) cost ~1.6x per row: shorter strips there keep the launch balanced
+                const int rb_edge = std::min(rb, edge_rows(rb));
+                fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], bt, c->pitch, c->n, lo, hi, rb, rb_edge);
                 first = last;
             }
         }
@@ -937,6 +950,10 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
     case FLUID_PARAM_TB_ROWS:
         if (value < 0) return fail(FLUID_E_INVALID, "TB_ROWS must be >= 0");
         c->tb_rows = value;
+        return FLUID_OK;
+    case FLUID_PARAM_TB_EDGE_ROWS_PCT:
+        if (value < 0 || value > 100) return fail(FLUID_E_INVALID, "TB_EDGE_ROWS_PCT must be in [0,100]");
+        c->tb_edge_pct = value;
         return FLUID_OK;
     case FLUID_PARAM_TB_MIN_CELLS:
         if (value < 0) return fail(FLUID_E_INVALID, "TB_MIN_CELLS must be >= 0");

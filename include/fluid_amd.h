@@ -56,6 +56,8 @@ enum {
     FLUID_PARAM_TB_FAST_DIVISION = 3 /* 1 (default): FLUID_JACOBI_TB may replace x/beta by an exactly equivalent
                                       reciprocal multiply, after proving the equivalence for that beta on all
                                       2^32 float inputs on the device; 0: always divide                  */
+    ,FLUID_PARAM_TB_EDGE_ROWS_PCT = 5 /* strip height of the two windows that carry the ghost columns, in % of
+                                      the interior windows' (default 40; 0 = same): load balance only  */
     ,FLUID_PARAM_TB_MIN_CELLS = 4  /* FLUID_JACOBI_TB fuses sweeps only on slabs of at least this many cells
                                       (default 1 500 000); smaller ones run one-thread-per-cell sweeps   */
 };

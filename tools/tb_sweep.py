@@ -19,6 +19,8 @@ x = rng.random((n + 2, n + 2), dtype=np.float32)
 with F.FluidSolver(n, jacobi=capi.JACOBI_TB) as s:
     s.upload(u=x, v=x)
     a, b = F.coefficients(n, 0.016, 0.0025)
+    if os.environ.get('TB_EDGE'):
+        s.set_param(capi.PARAM_TB_EDGE_ROWS_PCT, int(os.environ['TB_EDGE']))
     for T in Ts:
         s.set_param(capi.PARAM_TB_MAX_SWEEPS, T)
         HL = (T + 3) // 4
@@ -35,7 +37,7 @@ with F.FluidSolver(n, jacobi=capi.JACOBI_TB) as s:
                 t = s.timing_read(reset=True)
                 s.timing_enable(False)
                 out.append(t["jacobi_ms"] * 1e3 / t["sweeps"])
-            strips = -(-n // rows)
+            strips = -(-n // rows) if rows else 0      # rows == 0: the library's own choice
             blocks = nwin * (-(-strips // 4))
             print("T=%d rows=%3d  waves=%5d blocks=%4d  us/sweep: div %.2f  mul %.2f" % (
                 T, rows, strips * nwin, blocks, out[0], out[1]), flush=True)
