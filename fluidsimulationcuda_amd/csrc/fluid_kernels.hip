@@ -802,19 +802,40 @@ __device__ __forceinline__ float wave_max(float m)
     return m;
 }
 
+// wave maxima -> block maximum (LDS) -> ONE atomic per block: contended atomics on a single word
+// serialise at ~12 ns each, so one per wave from thousands of waves costs more than the reduction.
+__device__ __forceinline__ void block_max_to(unsigned int* __restrict__ result, float m)
+{
+    __shared__ float part[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        atomicMax(result, __float_as_uint(m));
+    }
+}
+
+// one workgroup per group of rows, whole float4 vectors (columns beyond 1..n masked out)
 template <typename S>
 __global__ __launch_bounds__(256) void k_absmax2(const S* __restrict__ u, const S* __restrict__ v, int pitch, int n,
                                                  int row_lo, int row_hi, unsigned int* __restrict__ result)
 {
     const size_t P = (size_t)pitch;
+    const int nvec = (n + 3) >> 2;
     float m = 0.0f;
-    for (int i = row_lo + blockIdx.y; i < row_hi; i += gridDim.y)
-        for (int j = 1 + blockIdx.x * 256 + threadIdx.x; j <= n; j += gridDim.x * 256) {
-            const size_t c = (size_t)i * P + XOFF + j;
-            m = fmaxf(m, fmaxf(fabsf(ld1(u + c)), fabsf(ld1(v + c))));
+    for (int i = row_lo + blockIdx.x; i < row_hi; i += gridDim.x)
+        for (int k = threadIdx.x; k < nvec; k += 256) {
+            const size_t c = (size_t)i * P + XOFF + 1 + 4 * (size_t)k;
+            const float4 a = ld4(u + c), b = ld4(v + c);
+            const int last = n - (1 + 4 * k);            // components 0..last are columns <= n
+            float t = fmaxf(fabsf(a.x), fabsf(b.x));
+            if (last >= 1) t = fmaxf(t, fmaxf(fabsf(a.y), fabsf(b.y)));
+            if (last >= 2) t = fmaxf(t, fmaxf(fabsf(a.z), fabsf(b.z)));
+            if (last >= 3) t = fmaxf(t, fmaxf(fabsf(a.w), fabsf(b.w)));
+            m = fmaxf(m, t);
         }
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(result, __float_as_uint(m));
+    block_max_to(result, m);
 }
 
 template <typename S>
@@ -824,14 +845,13 @@ __global__ __launch_bounds__(256) void k_residual(const S* __restrict__ x, const
 {
     const size_t P = (size_t)pitch;
     float m = 0.0f;
-    for (int i = row_lo + blockIdx.y; i < row_hi; i += gridDim.y)
-        for (int j = 1 + blockIdx.x * 256 + threadIdx.x; j <= n; j += gridDim.x * 256) {
+    for (int i = row_lo + blockIdx.x; i < row_hi; i += gridDim.x)
+        for (int j = 1 + threadIdx.x; j <= n; j += 256) {
             const size_t c = (size_t)i * P + XOFF + j;
             const float nb = ld1(x + c - 1) + ld1(x + c + 1) + ld1(x + c - P) + ld1(x + c + P);
             m = fmaxf(m, fabsf(beta * ld1(x + c) - alpha * nb - ld1(x0 + c)));
         }
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(result, __float_as_uint(m));
+    block_max_to(result, m);
 }
 
 // ---------------------------------------------------------------------------
@@ -957,9 +977,8 @@ void launch_absmax2(hipStream_t s, int st, const void* u, const void* v, int pit
                     unsigned int* result)
 {
     if (row_hi <= row_lo) return;
-    const unsigned gy = (unsigned)(row_hi - row_lo) < 512u ? (unsigned)(row_hi - row_lo) : 512u;
-    const unsigned gx = cdiv(n, 256) < 8u ? cdiv(n, 256) : 8u;
-    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_absmax2<S>, dim3(gx, gy), dim3(256), 0, s, (const S*)u, (const S*)v, pitch,
+    const unsigned blocks = (unsigned)(row_hi - row_lo) < 1024u ? (unsigned)(row_hi - row_lo) : 1024u;
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_absmax2<S>, dim3(blocks), dim3(256), 0, s, (const S*)u, (const S*)v, pitch,
                                             n, row_lo, row_hi, result));
 }
 
@@ -967,9 +986,8 @@ void launch_residual(hipStream_t s, int st, const void* x, const void* x0, int p
                      float alpha, float beta, unsigned int* result)
 {
     if (row_hi <= row_lo) return;
-    const unsigned gy = (unsigned)(row_hi - row_lo) < 512u ? (unsigned)(row_hi - row_lo) : 512u;
-    const unsigned gx = cdiv(n, 256) < 8u ? cdiv(n, 256) : 8u;
-    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_residual<S>, dim3(gx, gy), dim3(256), 0, s, (const S*)x, (const S*)x0, pitch,
+    const unsigned blocks = (unsigned)(row_hi - row_lo) < 1024u ? (unsigned)(row_hi - row_lo) : 1024u;
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_residual<S>, dim3(blocks), dim3(256), 0, s, (const S*)x, (const S*)x0, pitch,
                                             n, row_lo, row_hi, alpha, beta, result));
 }
 
