@@ -645,19 +645,23 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
         return op_advect(c, 0, D, D0, U, V, dt);
     }
     // Slabs: each advect needs the global max |velocity| on the host -- a pipeline drain.  The
-    // density diffusion depends on nothing in between, so its sweeps are enqueued behind each
-    // reduction (in two parts) and the GPU stays busy while the host waits and talks to its peers.
-    const int part1 = std::min(iters, ((iters * 3 / 5) + 7) / 8 * 8), part2 = iters - part1;
-    TRY(op_diffuse_batch(c, all, 2, iters));
+    // density diffusion depends on nothing in between, so most of it rides in the same launches as
+    // u and v (the fused kernel is latency-bound: a third field per launch is nearly free) and its
+    // last sweeps are held back, one launch behind each reduction, so the GPU stays busy while the
+    // host waits and talks to its peers.
+    const int rest = std::min(iters, 16), head = iters - rest;          // multiples of 8 for iters = 40
+    const int fill1 = std::min(rest, 8), fill2 = rest - fill1;
+    if (head > 0) TRY(op_diffuse_batch(c, all, 3, head));
+    if (rest > 0) TRY(op_diffuse_batch(c, all, 2, rest));
     TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
     TRY(vmax_begin(c, U0, V0));
-    TRY(op_diffuse_batch(c, all + 2, 1, part1));
+    if (fill1 > 0) TRY(op_diffuse_batch(c, all + 2, 1, fill1));
     TRY(advect_halo(c, {U0, V0}, dt0));
     TRY(op_advect(c, 1, U, U0, U0, V0, dt));
     TRY(op_advect(c, 2, V, V0, U0, V0, dt));
     TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters));
     TRY(vmax_begin(c, U, V));
-    TRY(op_diffuse_batch(c, all + 2, 1, part2));
+    if (fill2 > 0) TRY(op_diffuse_batch(c, all + 2, 1, fill2));
     TRY(advect_halo(c, {D0}, dt0));
     return op_advect(c, 0, D, D0, U, V, dt);
 }
