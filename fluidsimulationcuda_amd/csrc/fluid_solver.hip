@@ -69,6 +69,7 @@ struct fluid_ctx {
     int variant = fluid::JACOBI_TB;
     int tb_max_t = 8, tb_rows = 0, num_cu = 256;   // temporal blocking: sweeps/launch cap, rows/strip (0 = auto)
     long long tb_min_cells = 1500000;              // smaller slabs use single-sweep launches
+    int tb_blocks_per_cu = 2;                      // resident 256-thread blocks per CU the fused kernel is built for
     int tb_edge_pct = 40;                          // strip height of the two edge windows, % of the others'
     bool fast_div = true;                          // allow division modes 1/2 (each beta proven on the device first)
     std::unordered_map<unsigned, int> div_mode;    // beta bits -> proven division mode
@@ -428,7 +429,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                     // one round stop at 80 rows (160 for a batch), past which more strips win again.
                     const int HL = (T + 3) / 4, VS = 64 - 2 * HL;
                     const long long windows = ((c->n + 3) / 4 + VS - 1) / VS;
-                    const long long room = (long long)c->num_cu * (T >= 8 ? 2 : 3) * 92 / 100;
+                    const long long room = (long long)c->num_cu * (T >= 8 ? c->tb_blocks_per_cu : 3) * 92 / 100;
                     const long long rows_n = hi - lo;
                     auto blocks = [&](int r) {
                         const long long si = (rows_n + r - 1) / r, se = (rows_n + edge_rows(r) - 1) / edge_rows(r);
