@@ -437,6 +437,8 @@ struct TbArgs {
     unsigned ld_off;      // byte offset of this lane's float4 in row 0 (kBufOff: lane loads nothing)
     unsigned st_off;      // same for the float4 store (kBufOff unless the lane owns interior or ghost columns)
     unsigned row_bytes;
+    unsigned m_lg;        // all ones in the lane whose .w is ghost column 0, else 0
+    unsigned m_r0, m_r1, m_r2, m_r3;   // all ones in the lane AND component that is ghost column n+1
     size_t P;
     int n, q_lo, q_hi, t_ld, cg, last;
     float alpha, beta;
@@ -488,22 +490,31 @@ __global__ __launch_bounds__(256) void k_validate_div(float beta, float arg, dou
     if (n) atomicAdd(bad, n);
 }
 
-// ghost columns of one freshly computed row (set_bnd, FluidSequential.c:65-66);
-// v1 / vn return column 1 / column n of the row (for the corners).
-template <typename S>
-__device__ __forceinline__ void tb_fix_columns(float4& G, const TbArgs<S>& a, float& v1, float& vn)
+// ghost columns of one freshly computed row (set_bnd, FluidSequential.c:65-66), edge windows only.
+// Branch-free: per-lane bit masks pick the one lane/component that is a ghost column and replace it
+// by its (sign-flipped) interior neighbour; every other lane and component passes through unchanged.
+// (Uniform branches here cost an edge-window wave ~2.7x an interior wave per step and made the two
+// edge windows the tail of every launch.)  v1 / vn return column 1 / column n of the row, which the
+// final stage needs for the corner cells.
+__device__ __forceinline__ float bitsel(unsigned mask, float a, float b)      // mask ? a : b, per bit
 {
-    if (a.left_edge) {
-        v1 = lane_above0(G.x);
-        if (a.is_lg) G.w = fxor(v1, a.sx);
-    }
-    if (a.right_edge) {
-        if (a.cg == 0) {
-            vn = lane_below0(G.w);
-            if (a.is_rg) G.x = fxor(vn, a.sx);
-        } else if (a.cg == 1) { vn = G.x; if (a.is_rg) G.y = fxor(vn, a.sx);
-        } else if (a.cg == 2) { vn = G.y; if (a.is_rg) G.z = fxor(vn, a.sx);
-        } else                { vn = G.z; if (a.is_rg) G.w = fxor(vn, a.sx); }
+    return __uint_as_float((__float_as_uint(a) & mask) | (__float_as_uint(b) & ~mask));
+}
+
+template <typename S>
+__device__ __forceinline__ void tb_fix_columns(float4& G, const TbArgs<S>& a, float& v1, float& vn, bool need_corners)
+{
+    const float ox = G.x, oy = G.y, oz = G.z, ow = G.w;
+    const float from_right = lane_above0(ox);            // column 1 as seen from the lane holding column 0
+    const float from_left = lane_below0(ow);             // column n as seen from the next lane (n % 4 == 0)
+    G.w = bitsel(a.m_lg, fxor(from_right, a.sx), bitsel(a.m_r3, fxor(oz, a.sx), ow));
+    G.x = bitsel(a.m_r0, fxor(from_left, a.sx), ox);
+    G.y = bitsel(a.m_r1, fxor(ox, a.sx), oy);
+    G.z = bitsel(a.m_r2, fxor(oy, a.sx), oz);
+    if (need_corners) {          // folds to a constant once the stage loop is unrolled
+        v1 = from_right;
+        vn = __uint_as_float((__float_as_uint(from_left) & a.m_r0) | (__float_as_uint(ox) & a.m_r1) |
+                             (__float_as_uint(oy) & a.m_r2) | (__float_as_uint(oz) & a.m_r3));
     }
 }
 
@@ -549,10 +560,10 @@ __device__ __forceinline__ void tb_qshift(float4 (&Q)[N])
 
 // One time step.  Ring s (s = 0..T-1) holds three consecutive rows of "x after
 // s sweeps"; at phase PH its slots are up = PH, me = PH+1, fresh = PH+2 (mod 3).
-// WALL = false: the strip is far enough from rows 0 / n+1 that every row a later
-// stage needs is interior -- a branch-free body.  WALL = true: per-stage checks,
-// ghost rows of each stage regenerated from its rows 1 / n.
-template <int T, int DIVMODE, bool EDGE, bool WALL, int PH, typename S>
+// GEN = false: every row any stage touches at this step is interior -- a
+// branch-free body.  GEN = true (the few steps of a wall strip that sit on rows
+// 0 / n+1): per-stage checks, ghost rows of each stage regenerated from its rows 1 / n.
+template <int T, int DIVMODE, bool EDGE, bool WALL, bool GEN, int PH, typename S>
 __device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T + 1], float4 (&PX)[3], float4 (&PQ)[3],
                                         const TbArgs<S>& a)
 {
@@ -565,21 +576,25 @@ __device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T 
         PX[PH] = buf_ld4(a.xc, a.bx, off);
         PQ[PH] = buf_ld4(a.rc, a.br, off);
     }
+    if constexpr (!GEN) {
 #pragma unroll
-    for (int s = 1; s <= T; ++s) {
-        const int q = t - s;                             // row this stage produces now (wave-uniform)
-        if (!WALL) {
+        for (int s = 1; s <= T; ++s) {
+            const int q = t - s;                         // row this stage produces now (wave-uniform)
             float4 G = tb_stencil<DIVMODE>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.beta, a.yd);
             float v1 = 0.f, vn = 0.f;
-            if (EDGE) tb_fix_columns(G, a, v1, vn);
+            if (EDGE) tb_fix_columns(G, a, v1, vn, WALL && s == T);
             if (s < T) W[s][FR] = G;
-            else tb_store<EDGE, false>(G, q, (q >= a.q_lo) & (q < a.q_hi), a, v1, vn);
-        } else {
-            // ring writes stay unconditional (selected values), so the rings stay in registers
+            else tb_store<EDGE, WALL>(G, q, (q >= a.q_lo) & (q < a.q_hi), a, v1, vn);
+        }
+    } else {
+        // ring writes stay unconditional (selected values), so the rings stay in registers
+#pragma unroll
+        for (int s = 1; s <= T; ++s) {
+            const int q = t - s;
             const bool interior = (q >= 1 && q <= a.n);
             float4 G = tb_stencil<DIVMODE>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.beta, a.yd);
             float v1 = 0.f, vn = 0.f;
-            if (EDGE) tb_fix_columns(G, a, v1, vn);
+            if (EDGE) tb_fix_columns(G, a, v1, vn, s == T);
             if (s < T) {
                 const float4 me = W[s][ME];
                 const float4 flipped_me = fxor4(me, a.sy);   // ghost row n+1 of this stage = flipped row n
@@ -614,11 +629,30 @@ __device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs<S>& a)
         PX[d] = buf_ld4(a.xc, a.bx, off);
         PQ[d] = buf_ld4(a.rc, a.br, off);
     }
-    // whole triples only: up to two surplus steps load nothing (t > t_ld) and store nothing (q >= q_hi)
-    for (int t = t0; t <= t1; t += 3) {
-        tb_step<T, DIVMODE, EDGE, WALL, 0>(t, W, Q, PX, PQ, a);
-        tb_step<T, DIVMODE, EDGE, WALL, 1>(t + 1, W, Q, PX, PQ, a);
-        tb_step<T, DIVMODE, EDGE, WALL, 2>(t + 2, W, Q, PX, PQ, a);
+    // whole triples only: up to two surplus steps load nothing (t > t_ld) and store nothing (q >= q_hi).
+    // A step is "interior" when the rows its stages produce, t-T .. t-1, all lie in 1..n and no stage
+    // below the last is on row 1 (whose ghost row it would have to regenerate): T+1 <= t <= n+1.  Wall
+    // strips run the general body only for the triples that contain another kind of step -- about
+    // T/3 of them per wall -- as three loops, so neither body pays for the other's registers.
+    int t = t0;
+    if constexpr (WALL) {
+        for (; t <= t1 && t < T + 1; t += 3) {
+            tb_step<T, DIVMODE, EDGE, WALL, true, 0>(t, W, Q, PX, PQ, a);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 1>(t + 1, W, Q, PX, PQ, a);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 2>(t + 2, W, Q, PX, PQ, a);
+        }
+    }
+    for (; t <= t1 && (!WALL || t + 1 <= a.n); t += 3) {
+        tb_step<T, DIVMODE, EDGE, WALL, false, 0>(t, W, Q, PX, PQ, a);
+        tb_step<T, DIVMODE, EDGE, WALL, false, 1>(t + 1, W, Q, PX, PQ, a);
+        tb_step<T, DIVMODE, EDGE, WALL, false, 2>(t + 2, W, Q, PX, PQ, a);
+    }
+    if constexpr (WALL) {
+        for (; t <= t1; t += 3) {
+            tb_step<T, DIVMODE, EDGE, WALL, true, 0>(t, W, Q, PX, PQ, a);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 1>(t + 1, W, Q, PX, PQ, a);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 2>(t + 2, W, Q, PX, PQ, a);
+        }
     }
 }
 
@@ -682,6 +716,11 @@ __global__ __launch_bounds__(256, (T <= 4 ? 3 : 2)) void k_jacobi_tb(TbBatch bat
     a.st_int = a.own && k >= 0 && k < nvec;              // stores interior columns
     a.st_rg_lane = a.is_rg && (a.own || k == nvec);      // stores ghost column n+1 (exactly one lane grid-wide)
     a.last = n - (1 + 4 * k);                            // component of column n in this lane (if 0..3)
+    a.m_lg = a.is_lg ? 0xFFFFFFFFu : 0u;
+    a.m_r0 = (a.is_rg && a.cg == 0) ? 0xFFFFFFFFu : 0u;
+    a.m_r1 = (a.is_rg && a.cg == 1) ? 0xFFFFFFFFu : 0u;
+    a.m_r2 = (a.is_rg && a.cg == 2) ? 0xFFFFFFFFu : 0u;
+    a.m_r3 = (a.is_rg && a.cg == 3) ? 0xFFFFFFFFu : 0u;
     // lanes that store: owners of interior columns (the ragged last vector included), the lane whose
     // .w is ghost column 0 and the lane holding ghost column n+1; surplus components go to pads
     a.st_off = (a.ld_ok && (a.st_int || a.is_lg || a.st_rg_lane)) ? a.ld_off : kBufOff;
