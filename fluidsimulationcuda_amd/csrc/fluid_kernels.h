@@ -23,7 +23,7 @@ struct TbBatch {
     const void* x[3];
     const void* x0[3];
     void* out[3];
-    float alpha[3], beta[3];     // beta: divisor, or its exact reciprocal in division mode 1
+    float alpha[3], beta[3];     // beta: divisor, or its exact reciprocal in division mode 4
     double yd[3];                // RN64(1/beta) for division mode 2
     int b[3];
     int x_zero[3];               // first guess known to be all +0: never read
@@ -34,7 +34,7 @@ void launch_set_bnd(hipStream_t s, int st, void* f, int pitch, int n, int b);
 void launch_add_source(hipStream_t s, int st, void* x, const void* src, int pitch, int row_lo, int row_hi, float dt);
 void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void* x0, void* out, int pitch, int n,
                    int row_lo, int row_hi, float alpha, float beta, int b);
-void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, const TbBatch& batch, int pitch, int n, int row_lo,
+void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const TbBatch& batch, int pitch, int n, int row_lo,
                       int row_hi, int rb, int rb_edge);
 void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, double yd, unsigned long long* bad);
 void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u, const void* v, int pitch, int n,

@@ -419,6 +419,7 @@ __global__ __launch_bounds__(256) void k_jacobi_stream(const S* __restrict__ x, 
 // DIVMODE 1: beta is a power of two and `beta` carries its exact reciprocal:
 //   (..)*rbeta is the same correctly rounded result for every input (pressure
 //   solve: beta = 4).
+// DIVMODE 4: DIVMODE 1 with alpha == 1.0f, whose multiplication is the identity and is left out.
 // DIVMODE 2: (float)((double)(..) * yd) with yd = RN64(1/beta).  The double
 //   product is within 2^-52 relative of the true quotient, while a quotient of two
 //   floats is never that close to a float rounding boundary (the boundary would
@@ -428,49 +429,148 @@ __global__ __launch_bounds__(256) void k_jacobi_stream(const S* __restrict__ x, 
 //   on a denormal midpoint, possible for a few even-integer-like beta -- is why
 //   the solver proves each beta on the device before using this mode:
 //   k_validate_div compares it with a/beta for all 2^32 inputs (about 6 op times).
-template <typename S>
+// One lane's share of a row: NV consecutive columns (NV = 2 or 4).
+template <int NV>
+struct Vec {
+    float c[NV];
+};
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef half_t half2_t __attribute__((ext_vector_type(2)));
+
+template <int NV>
+__device__ __forceinline__ Vec<NV> buf_ldv(const float*, __amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    Vec<NV> v;
+    if constexpr (NV == 4) {
+        const uint4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        v.c[0] = __uint_as_float(u.x); v.c[1] = __uint_as_float(u.y); v.c[2] = __uint_as_float(u.z); v.c[3] = __uint_as_float(u.w);
+    } else {
+        const uint2_t u = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        v.c[0] = __uint_as_float(u.x); v.c[1] = __uint_as_float(u.y);
+    }
+    return v;
+}
+template <int NV>
+__device__ __forceinline__ Vec<NV> buf_ldv(const half_t*, __amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    Vec<NV> v;
+    if constexpr (NV == 4) {
+        const uint2_t u = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        half4_t h;
+        __builtin_memcpy(&h, &u, 8);
+        v.c[0] = keep_f32((float)h.x); v.c[1] = keep_f32((float)h.y); v.c[2] = keep_f32((float)h.z); v.c[3] = keep_f32((float)h.w);
+    } else {
+        const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+        half2_t h;
+        __builtin_memcpy(&h, &u, 4);
+        v.c[0] = keep_f32((float)h.x); v.c[1] = keep_f32((float)h.y);
+    }
+    return v;
+}
+template <int NV>
+__device__ __forceinline__ void buf_stv(float*, __amdgpu_buffer_rsrc_t r, unsigned off, const Vec<NV>& v)
+{
+    if constexpr (NV == 4) {
+        uint4_t u;
+        u.x = __float_as_uint(v.c[0]); u.y = __float_as_uint(v.c[1]); u.z = __float_as_uint(v.c[2]); u.w = __float_as_uint(v.c[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, 0);
+    } else {
+        uint2_t u;
+        u.x = __float_as_uint(v.c[0]); u.y = __float_as_uint(v.c[1]);
+        __builtin_amdgcn_raw_buffer_store_b64(u, r, off, 0, 0);
+    }
+}
+template <int NV>
+__device__ __forceinline__ void buf_stv(half_t*, __amdgpu_buffer_rsrc_t r, unsigned off, const Vec<NV>& v)
+{
+    if constexpr (NV == 4) {
+        half4_t h;
+        h.x = (half_t)keep_f32(v.c[0]); h.y = (half_t)keep_f32(v.c[1]); h.z = (half_t)keep_f32(v.c[2]); h.w = (half_t)keep_f32(v.c[3]);
+        uint2_t u;
+        __builtin_memcpy(&u, &h, 8);
+        __builtin_amdgcn_raw_buffer_store_b64(u, r, off, 0, 0);
+    } else {
+        half2_t h;
+        h.x = (half_t)keep_f32(v.c[0]); h.y = (half_t)keep_f32(v.c[1]);
+        unsigned u;
+        __builtin_memcpy(&u, &h, 4);
+        __builtin_amdgcn_raw_buffer_store_b32(u, r, off, 0, 0);
+    }
+}
+
+template <typename S, int NV>
 struct TbArgs {
     const S* xc;          // x   + column offset of this lane
     const S* rc;          // x0  + column offset
     S* oc;                // out + column offset
     __amdgpu_buffer_rsrc_t bx, br, bo;   // the three fields as range-checked buffers
-    unsigned ld_off;      // byte offset of this lane's float4 in row 0 (kBufOff: lane loads nothing)
-    unsigned st_off;      // same for the float4 store (kBufOff unless the lane owns interior or ghost columns)
+    unsigned ld_off;      // byte offset of this lane's vector in row 0 (kBufOff: lane loads nothing)
+    unsigned st_off;      // same for the store (kBufOff unless the lane owns interior or ghost columns)
     unsigned row_bytes;
-    unsigned m_lg;        // all ones in the lane whose .w is ghost column 0, else 0
-    unsigned m_r0, m_r1, m_r2, m_r3;   // all ones in the lane AND component that is ghost column n+1
-    size_t P;
-    int n, q_lo, q_hi, t_ld, cg, last;
+    unsigned m_lg;        // all ones in the lane whose last component is ghost column 0, else 0
+    unsigned m_r[NV];     // all ones in the lane AND component that is ghost column n+1
+    int n, q_lo, q_hi, cg;
     float alpha, beta;
     double yd;            // DIVMODE 2: 1/beta rounded to double
     unsigned sx, sy;      // sign masks: flip across vertical / horizontal walls
-    bool ld_ok, own, st_int, st_rg_lane, is_lg, is_rg, left_edge, right_edge;
+    bool st_rg_lane, is_lg;
 };
 
 __device__ __forceinline__ float fxor(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) ^ m); }
-__device__ __forceinline__ float4 fxor4(const float4& v, unsigned m)
+template <int NV>
+__device__ __forceinline__ Vec<NV> fxorv(const Vec<NV>& v, unsigned m)
 {
-    return make_float4(fxor(v.x, m), fxor(v.y, m), fxor(v.z, m), fxor(v.w, m));
+    Vec<NV> o;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) o.c[c] = fxor(v.c[c], m);
+    return o;
 }
 
+// (r + alpha*nb) / beta for one cell (the validator) and for a pair of cells (the kernel; same
+// operations, the compiler emits the packed form of each).
 template <int DIVMODE>
 __device__ __forceinline__ float tb_div(float num, float beta, double yd)
 {
     if (DIVMODE == 0) return num / beta;
-    if (DIVMODE == 1) return num * beta;           // beta holds the exact reciprocal
+    if (DIVMODE == 4) return num * beta;           // beta holds the exact reciprocal
     return (float)((double)num * yd);
 }
-
 template <int DIVMODE>
-__device__ __forceinline__ float4 tb_stencil(const float4& up, const float4& me, const float4& dn, const float4& r,
-                                             float alpha, float beta, double yd)
+__device__ __forceinline__ v2f tb_div2(v2f num, float beta, double yd)
 {
-    float4 G;
-    float nb;
-    nb = lane_below0(me.w) + me.y; nb = nb + up.x; nb = nb + dn.x; G.x = tb_div<DIVMODE>(r.x + alpha * nb, beta, yd);
-    nb = me.x + me.z;              nb = nb + up.y; nb = nb + dn.y; G.y = tb_div<DIVMODE>(r.y + alpha * nb, beta, yd);
-    nb = me.y + me.w;              nb = nb + up.z; nb = nb + dn.z; G.z = tb_div<DIVMODE>(r.z + alpha * nb, beta, yd);
-    nb = me.z + lane_above0(me.x); nb = nb + up.w; nb = nb + dn.w; G.w = tb_div<DIVMODE>(r.w + alpha * nb, beta, yd);
+    if constexpr (DIVMODE == 4) return num * beta;
+    else return (v2f){tb_div<DIVMODE>(num.x, beta, yd), tb_div<DIVMODE>(num.y, beta, yd)};
+}
+
+// One lane's vector of one stage.  Its columns are worked on in pairs (0,1), (2,3), which is how every
+// row already sits in registers (a load fills aligned registers, each result is written as aligned
+// pairs): the horizontal sum l+r is one scalar add per column -- the two at the ends of the vector
+// reach into the neighbouring lane through DPP -- whose results land in adjacent registers, and
+// everything after it is one packed instruction per pair (v_pk_add_f32 x3, v_pk_mul_f32 x1..2).
+// 3 to 3.5 VALU instructions per cell instead of 6.5: a wave issues about one instruction per 4.6
+// cycles whatever its kind (tools/ubench/valu_cost.hip), so instructions are what to save.
+// Operand order and roundings are those of FluidSequential.c:93-94.
+template <int DIVMODE, int NV>
+__device__ __forceinline__ Vec<NV> tb_stencil(const Vec<NV>& up, const Vec<NV>& me, const Vec<NV>& dn, const Vec<NV>& r,
+                                              float alpha, float beta, double yd)
+{
+    float h[NV];
+    h[0] = lane_below0(me.c[NV - 1]) + me.c[1];
+#pragma unroll
+    for (int c = 1; c < NV - 1; ++c) h[c] = me.c[c - 1] + me.c[c + 1];
+    h[NV - 1] = me.c[NV - 2] + lane_above0(me.c[0]);
+    Vec<NV> G;
+#pragma unroll
+    for (int p = 0; p < NV; p += 2) {
+        v2f s = {h[p], h[p + 1]};
+        s = s + (v2f){up.c[p], up.c[p + 1]};
+        s = s + (v2f){dn.c[p], dn.c[p + 1]};
+        if constexpr (DIVMODE != 4) s = s * alpha;       // mode 4: alpha == 1.0f, x * 1.0f is x
+        s = (v2f){r.c[p], r.c[p + 1]} + s;
+        s = tb_div2<DIVMODE>(s, beta, yd);
+        G.c[p] = s.x;
+        G.c[p + 1] = s.y;
+    }
     return G;
 }
 
@@ -501,60 +601,77 @@ __device__ __forceinline__ float bitsel(unsigned mask, float a, float b)      //
     return __uint_as_float((__float_as_uint(a) & mask) | (__float_as_uint(b) & ~mask));
 }
 
-template <typename S>
-__device__ __forceinline__ void tb_fix_columns(float4& G, const TbArgs<S>& a, float& v1, float& vn, bool need_corners)
+template <typename S, int NV>
+__device__ __forceinline__ void tb_fix_columns(Vec<NV>& G, const TbArgs<S, NV>& a, float& v1, float& vn, bool need_corners)
 {
-    const float ox = G.x, oy = G.y, oz = G.z, ow = G.w;
-    const float from_right = lane_above0(ox);            // column 1 as seen from the lane holding column 0
-    const float from_left = lane_below0(ow);             // column n as seen from the next lane (n % 4 == 0)
-    G.w = bitsel(a.m_lg, fxor(from_right, a.sx), bitsel(a.m_r3, fxor(oz, a.sx), ow));
-    G.x = bitsel(a.m_r0, fxor(from_left, a.sx), ox);
-    G.y = bitsel(a.m_r1, fxor(ox, a.sx), oy);
-    G.z = bitsel(a.m_r2, fxor(oy, a.sx), oz);
+    float o[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) o[c] = G.c[c];
+    const float from_right = lane_above0(o[0]);          // column 1 as seen from the lane holding column 0
+    const float from_left = lane_below0(o[NV - 1]);      // column n as seen from the next lane (n % NV == 0)
+    G.c[0] = bitsel(a.m_r[0], fxor(from_left, a.sx), o[0]);
+#pragma unroll
+    for (int c = 1; c < NV - 1; ++c) G.c[c] = bitsel(a.m_r[c], fxor(o[c - 1], a.sx), o[c]);
+    G.c[NV - 1] = bitsel(a.m_lg, fxor(from_right, a.sx), bitsel(a.m_r[NV - 1], fxor(o[NV - 2], a.sx), o[NV - 1]));
     if (need_corners) {          // folds to a constant once the stage loop is unrolled
         v1 = from_right;
-        vn = __uint_as_float((__float_as_uint(from_left) & a.m_r0) | (__float_as_uint(ox) & a.m_r1) |
-                             (__float_as_uint(oy) & a.m_r2) | (__float_as_uint(oz) & a.m_r3));
+        unsigned bits = __float_as_uint(from_left) & a.m_r[0];
+#pragma unroll
+        for (int c = 1; c < NV; ++c) bits |= __float_as_uint(o[c - 1]) & a.m_r[c];
+        vn = __uint_as_float(bits);
     }
 }
 
 // final stage: store row q, its ghost columns, and ghost rows / corners -- WITHOUT branches.
-// Every lane that holds anything to be stored writes its whole float4 through the range-checked
+// Every lane that holds anything to be stored writes its whole vector through the range-checked
 // buffer: the ragged last vector and the two ghost-column lanes spill their surplus components
 // into pad floats (never read as data), so edge windows issue the same single store per step as
 // interior ones; wall strips add the two ghost rows, enabled by a select on the offset.  A fixed
 // number of memory operations per step is what lets hipcc count them (see buf_ld4).
-template <bool EDGE, bool WALL, typename S>
-__device__ __forceinline__ void tb_store(const float4& G, int q, bool mine, const TbArgs<S>& a, float v1, float vn)
+template <bool EDGE, bool WALL, typename S, int NV>
+__device__ __forceinline__ void tb_store(const Vec<NV>& G, int q, bool mine, const TbArgs<S, NV>& a, float v1, float vn)
 {
     auto on = [](bool c, unsigned off) { return c ? off : kBufOff; };
-    buf_st4(a.oc, a.bo, on(mine, a.st_off) + (unsigned)q * a.row_bytes, G);
+    buf_stv<NV>(a.oc, a.bo, on(mine, a.st_off) + (unsigned)q * a.row_bytes, G);
     if (WALL) {
-        float4 g4 = fxor4(G, a.sy);                      // ghost row = flipped wall row ...
+        Vec<NV> g = fxorv<NV>(G, a.sy);                  // ghost row = flipped wall row ...
         if (EDGE) {                                      // ... except its two corner cells
             const float cl = 0.5f * (fxor(v1, a.sy) + fxor(v1, a.sx));
             const float cr = 0.5f * (fxor(vn, a.sy) + fxor(vn, a.sx));
-            if (a.is_lg) g4.w = cl;
-            if (a.st_rg_lane) {
-                if (a.cg == 0) g4.x = cr;
-                else if (a.cg == 1) g4.y = cr;
-                else if (a.cg == 2) g4.z = cr;
-                else g4.w = cr;
-            }
+            if (a.is_lg) g.c[NV - 1] = cl;
+#pragma unroll
+            for (int c = 0; c < NV; ++c)
+                if (a.st_rg_lane && a.cg == c) g.c[c] = cr;
         }
-        buf_st4(a.oc, a.bo, on(mine & (q == 1), a.st_off), g4);                                        // row 0
-        buf_st4(a.oc, a.bo, on(mine & (q == a.n), a.st_off) + (unsigned)(a.n + 1) * a.row_bytes, g4);  // row n+1
+        buf_stv<NV>(a.oc, a.bo, on(mine & (q == 1), a.st_off), g);                                        // row 0
+        buf_stv<NV>(a.oc, a.bo, on(mine & (q == a.n), a.st_off) + (unsigned)(a.n + 1) * a.row_bytes, g);  // row n+1
     }
+}
+
+// the hand-over of a prefetched row into the pipeline, as register moves the compiler cannot see
+// through (tb_step says why)
+template <int NV>
+__device__ __forceinline__ Vec<NV> take(const Vec<NV>& v)
+{
+    Vec<NV> o;
+#pragma unroll
+    for (int p = 0; p < NV; p += 2) {
+        v2f in = {v.c[p], v.c[p + 1]}, out;
+        asm("v_mov_b64 %0, %1" : "=v"(out) : "v"(in));
+        o.c[p] = out.x;
+        o.c[p + 1] = out.y;
+    }
+    return o;
 }
 
 // x0 queue shift as straight-line code (a loop here is recognised as memmove,
 // which pins the whole queue in scratch memory).
-template <int S, int N>
-__device__ __forceinline__ void tb_qshift(float4 (&Q)[N])
+template <int K, int N, int NV>
+__device__ __forceinline__ void tb_qshift(Vec<NV> (&Q)[N])
 {
-    if constexpr (S >= 1) {
-        Q[S] = Q[S - 1];
-        tb_qshift<S - 1, N>(Q);
+    if constexpr (K >= 1) {
+        Q[K] = Q[K - 1];
+        tb_qshift<K - 1, N, NV>(Q);
     }
 }
 
@@ -563,28 +680,37 @@ __device__ __forceinline__ void tb_qshift(float4 (&Q)[N])
 // GEN = false: every row any stage touches at this step is interior -- a
 // branch-free body.  GEN = true (the few steps of a wall strip that sit on rows
 // 0 / n+1): per-stage checks, ghost rows of each stage regenerated from its rows 1 / n.
-template <int T, int DIVMODE, bool EDGE, bool WALL, bool GEN, int PH, typename S>
-__device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T + 1], float4 (&PX)[3], float4 (&PQ)[3],
-                                        const TbArgs<S>& a)
+template <int T, int DIVMODE, bool EDGE, bool WALL, bool GEN, int PH, typename S, int NV>
+__device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[T + 1], Vec<NV> (&PX)[3], Vec<NV> (&PQ)[3],
+                                        const TbArgs<S, NV>& a)
 {
     constexpr int UP = PH % 3, ME = (PH + 1) % 3, FR = (PH + 2) % 3;
-    W[0][FR] = PX[PH];                                   // stage 0: row t of x (loaded three steps ago)
-    Q[0] = PQ[PH];
-    {   // refill the slot with row t+3: three steps of arithmetic cover the HBM latency.  Rows past
+    // stage 0: row t of x and x0, loaded three steps ago.  The hand-over is an opaque register move on
+    // purpose: a plain assignment lets the allocator rename the prefetch slot into the ring and pay
+    // for it with copies at the loop's back edge -- copies of rows still in flight, i.e. a wait for
+    // every outstanding load once per iteration.
+    __builtin_amdgcn_sched_barrier(0);                   // (and not hoisted into the previous step either)
+    W[0][FR] = take<NV>(PX[PH]);
+    Q[0] = take<NV>(PQ[PH]);
+    {   // refill the slot with row t+3: three steps of arithmetic cover the memory latency.  Rows past
         // the field's end and lanes past its width fall outside the buffer and read as 0.
         const unsigned off = a.ld_off + (unsigned)(t + 3) * a.row_bytes;
-        PX[PH] = buf_ld4(a.xc, a.bx, off);
-        PQ[PH] = buf_ld4(a.rc, a.br, off);
+        PX[PH] = buf_ldv<NV>(a.xc, a.bx, off);
+        PQ[PH] = buf_ldv<NV>(a.rc, a.br, off);
     }
+    // the loads must ISSUE here, three steps before their use: left to itself the scheduler sinks
+    // them to the end of the unrolled iteration (shorter live ranges) and the wave then waits out a
+    // full memory latency per iteration
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (!GEN) {
 #pragma unroll
         for (int s = 1; s <= T; ++s) {
             const int q = t - s;                         // row this stage produces now (wave-uniform)
-            float4 G = tb_stencil<DIVMODE>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.beta, a.yd);
+            Vec<NV> G = tb_stencil<DIVMODE, NV>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.beta, a.yd);
             float v1 = 0.f, vn = 0.f;
-            if (EDGE) tb_fix_columns(G, a, v1, vn, WALL && s == T);
+            if (EDGE) tb_fix_columns<S, NV>(G, a, v1, vn, WALL && s == T);
             if (s < T) W[s][FR] = G;
-            else tb_store<EDGE, WALL>(G, q, (q >= a.q_lo) & (q < a.q_hi), a, v1, vn);
+            else tb_store<EDGE, WALL, S, NV>(G, q, (q >= a.q_lo) & (q < a.q_hi), a, v1, vn);
         }
     } else {
         // ring writes stay unconditional (selected values), so the rings stay in registers
@@ -592,48 +718,56 @@ __device__ __forceinline__ void tb_step(int t, float4 (&W)[T][3], float4 (&Q)[T 
         for (int s = 1; s <= T; ++s) {
             const int q = t - s;
             const bool interior = (q >= 1 && q <= a.n);
-            float4 G = tb_stencil<DIVMODE>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.beta, a.yd);
+            Vec<NV> G = tb_stencil<DIVMODE, NV>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.beta, a.yd);
             float v1 = 0.f, vn = 0.f;
-            if (EDGE) tb_fix_columns(G, a, v1, vn, s == T);
+            if (EDGE) tb_fix_columns<S, NV>(G, a, v1, vn, s == T);
             if (s < T) {
-                const float4 me = W[s][ME];
-                const float4 flipped_me = fxor4(me, a.sy);   // ghost row n+1 of this stage = flipped row n
-                const float4 flipped_g = fxor4(G, a.sy);     // ghost row 0 of this stage = flipped row 1
+                const Vec<NV> me = W[s][ME];
+                const Vec<NV> flipped_me = fxorv<NV>(me, a.sy);  // ghost row n+1 of this stage = flipped row n
+                const Vec<NV> flipped_g = fxorv<NV>(G, a.sy);    // ghost row 0 of this stage = flipped row 1
                 const bool bot_ghost = (q == a.n + 1), top_ghost = (q == 1);
-                W[s][FR] = make_float4(bot_ghost ? flipped_me.x : G.x, bot_ghost ? flipped_me.y : G.y,
-                                       bot_ghost ? flipped_me.z : G.z, bot_ghost ? flipped_me.w : G.w);
-                W[s][ME] = make_float4(top_ghost ? flipped_g.x : me.x, top_ghost ? flipped_g.y : me.y,
-                                       top_ghost ? flipped_g.z : me.z, top_ghost ? flipped_g.w : me.w);
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    W[s][FR].c[c] = bot_ghost ? flipped_me.c[c] : G.c[c];
+                    W[s][ME].c[c] = top_ghost ? flipped_g.c[c] : me.c[c];
+                }
             } else {
-                tb_store<EDGE, true>(G, q, interior & (q >= a.q_lo) & (q < a.q_hi), a, v1, vn);
+                tb_store<EDGE, true, S, NV>(G, q, interior & (q >= a.q_lo) & (q < a.q_hi), a, v1, vn);
             }
         }
     }
-    tb_qshift<T, T + 1>(Q);
+    tb_qshift<T, T + 1, NV>(Q);
 }
 
-template <int T, int DIVMODE, bool EDGE, bool WALL, typename S>
-__device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs<S>& a)
+template <int T, int DIVMODE, bool EDGE, bool WALL, typename S, int NV>
+__device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs<S, NV>& a)
 {
-    float4 W[T][3], Q[T + 1], PX[3], PQ[3];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    Vec<NV> W[T][3], Q[T + 1], PX[3], PQ[3];
+    Vec<NV> zero;
 #pragma unroll
-    for (int s = 0; s < T; ++s) { W[s][0] = zero4; W[s][1] = zero4; W[s][2] = zero4; }
+    for (int c = 0; c < NV; ++c) zero.c[c] = 0.f;
 #pragma unroll
-    for (int s = 0; s <= T; ++s) Q[s] = zero4;
+    for (int s = 0; s < T; ++s) { W[s][0] = zero; W[s][1] = zero; W[s][2] = zero; }
+#pragma unroll
+    for (int s = 0; s <= T; ++s) Q[s] = zero;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {                        // rows t0, t0+1, t0+2 in flight before the first step
-        PX[d] = zero4;
-        PQ[d] = zero4;
         const unsigned off = a.ld_off + (unsigned)(t0 + d) * a.row_bytes;
-        PX[d] = buf_ld4(a.xc, a.bx, off);
-        PQ[d] = buf_ld4(a.rc, a.br, off);
+        PX[d] = buf_ldv<NV>(a.xc, a.bx, off);
+        PQ[d] = buf_ldv<NV>(a.rc, a.br, off);
+        // a store that stores nothing (offset out of range): the loop is entered with the same
+        // load, load, store sequence in flight that one of its iterations leaves behind, so the wait
+        // for a row at the top of the loop counts 7 younger operations on both paths into it instead
+        // of draining the queue
+        buf_stv<NV>(a.oc, a.bo, kBufOff, zero);
+        __builtin_amdgcn_sched_barrier(0);               // in this order
     }
-    // whole triples only: up to two surplus steps load nothing (t > t_ld) and store nothing (q >= q_hi).
-    // A step is "interior" when the rows its stages produce, t-T .. t-1, all lie in 1..n and no stage
-    // below the last is on row 1 (whose ghost row it would have to regenerate): T+1 <= t <= n+1.  Wall
-    // strips run the general body only for the triples that contain another kind of step -- about
-    // T/3 of them per wall -- as three loops, so neither body pays for the other's registers.
+    // whole triples only: up to two surplus steps load nothing (rows past the field) and store nothing
+    // (q >= q_hi).  A step is "interior" when the rows its stages produce, t-T .. t-1, all lie in 1..n
+    // and no stage below the last is on row 1 (whose ghost row it would have to regenerate):
+    // T+1 <= t <= n+1.  Wall strips run the general body only for the triples that contain another
+    // kind of step -- about T/3 of them per wall -- as three loops, so neither body pays for the
+    // other's registers.
     int t = t0;
     if constexpr (WALL) {
         for (; t <= t1 && t < T + 1; t += 3) {
@@ -656,89 +790,112 @@ __device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs<S>& a)
     }
 }
 
-// second launch-bound argument = waves per SIMD the register allocator must leave room for.
+// which (window, strip group) pairs exist (launch_jacobi_tb)
+struct TbGrid {
+    int inner_wins, inner_blocks, edge_wins, edge_blocks, first_right;
+};
+
+// waves per SIMD the register allocator must leave room for (second launch-bound argument): the
+// kernel hides its latencies (memory, dependent packed operations) only by running other waves
+constexpr int tb_waves_per_simd(int T, int NV) { return NV == 2 ? (T <= 8 ? 4 : 2) : (T <= 4 ? 3 : 2); }
+
 // blockIdx.z picks one of up to three independent solves of the same shape (u, v and density
 // diffusion): more waves per launch, hence taller strips and less pipeline-fill redundancy.
-template <int T, int DIVMODE, typename S>
-__global__ __launch_bounds__(256, (T <= 4 ? 3 : 2)) void k_jacobi_tb(TbBatch batch, int pitch, int n, int row_lo, int row_hi,
-                                                                    int rb, int rb_edge)
+template <int T, int DIVMODE, int NV, typename S>
+__global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbBatch batch, int pitch, int n, int row_lo,
+                                                                             int row_hi, int rb, int rb_edge, TbGrid g)
 {
+    // Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  The
+    // grid is one-dimensional, a multiple of 8 long, and renumbered so that XCD k works through the
+    // k-th contiguous eighth of the (window, strip group) list, windows fastest: the blocks an XCD
+    // runs at the same time are neighbouring windows of the same rows, and the columns they both
+    // read (2*HL lanes per window, a third of the reads at T = 16) are served by that XCD's L2
+    // instead of crossing the fabric twice.
+    // Only blocks that have rows are enumerated: interior windows x their strip groups first, then the
+    // edge windows (window 0 and the last one or two), which have more, shorter strips.
+    const unsigned per_xcd = gridDim.x >> 3;
+    unsigned vid = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (vid >= (unsigned)(g.inner_blocks + g.edge_blocks)) return;
+    int win, strip_group;
+    if (vid < (unsigned)g.inner_blocks) {
+        win = 1 + (int)(vid % (unsigned)g.inner_wins);
+        strip_group = (int)(vid / (unsigned)g.inner_wins);
+    } else {
+        vid -= (unsigned)g.inner_blocks;
+        const int e = (int)(vid % (unsigned)g.edge_wins);
+        strip_group = (int)(vid / (unsigned)g.edge_wins);
+        win = e == 0 ? 0 : g.first_right + e - 1;
+    }
     const S* __restrict__ x = static_cast<const S*>(batch.x[blockIdx.z]);
     const S* __restrict__ x0 = static_cast<const S*>(batch.x0[blockIdx.z]);
     S* __restrict__ out = static_cast<S*>(batch.out[blockIdx.z]);
     const float alpha = batch.alpha[blockIdx.z], beta = batch.beta[blockIdx.z];
     const double yd = batch.yd[blockIdx.z];
     const int b = batch.b[blockIdx.z];
-    constexpr int HL = (T + 3) / 4;
+    constexpr int HL = (T + NV - 1) / NV;                // lanes of overlap per side: T columns
     constexpr int VS = 64 - 2 * HL;
+    constexpr int C0 = (XOFF + 1) / NV;                  // vector index of column 1 within a row
+    static_assert((XOFF + 1) % NV == 0 && HL <= C0, "window overlap must fit the row's left pad");
     const int lane = threadIdx.x & 63;
     // the wave index is uniform, but anything derived from threadIdx is divergent to hipcc: readfirstlane
     // makes the strip bounds (and with them the loop control and the store conditions) scalar
-    const int strip = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int win = blockIdx.x;
+    const int strip = strip_group * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // the two windows that carry the ghost columns do extra work per stage; they get shorter strips
     // (rb_edge < rb, more of them) so that they do not finish long after everybody else
-    const int kg0 = n >> 2;
-    const bool edge_win = (win == 0) || ((kg0 >= win * VS - HL) && (kg0 < win * VS - HL + 64));
-    const int rbw = edge_win ? rb_edge : rb;
-    TbArgs<S> a;
+    const int kg = n / NV;                               // ghost column n+1 = component cg of vector kg
+    const bool left_edge = (win == 0);                                                  // wave-uniform
+    const bool right_edge = (kg >= win * VS - HL) && (kg < win * VS - HL + 64);         // wave-uniform
+    const bool edge = left_edge || right_edge;
+    const int rbw = edge ? rb_edge : rb;
+    TbArgs<S, NV> a;
     a.yd = yd;
     a.q_lo = row_lo + strip * rbw;                       // this wave's output rows [q_lo, q_hi)
     if (a.q_lo >= row_hi) return;                        // wave-uniform
     a.q_hi = min(a.q_lo + rbw, row_hi);
-    const int k = win * VS - HL + lane;                  // float4 index: columns 1+4k .. 4+4k
-    const int nvec = (n + 3) >> 2;
-    a.ld_ok = k <= (pitch >> 2) - 17;                    // k >= -HL >= -16 always
-    a.P = (size_t)pitch;
-    const ptrdiff_t cofs = (ptrdiff_t)(XOFF + 1) + 4 * (ptrdiff_t)(a.ld_ok ? k : 0);
+    const int k = win * VS - HL + lane;                  // vector index: columns 1+NV*k .. NV+NV*k
+    const int nvec = (n + NV - 1) / NV;
+    const bool ld_ok = k <= pitch / NV - C0 - 1;         // the whole vector lies inside the row (k >= -HL >= -C0 always)
+    const ptrdiff_t cofs = (ptrdiff_t)(XOFF + 1) + NV * (ptrdiff_t)(ld_ok ? k : 0);
     a.xc = x + cofs;
     a.rc = x0 + cofs;
     a.oc = out + cofs;
     {
-        const unsigned field_bytes = (unsigned)((size_t)(n + 2) * a.P * sizeof(S));    // < 2 GiB (launch_jacobi_tb)
+        const unsigned field_bytes = (unsigned)((size_t)(n + 2) * (size_t)pitch * sizeof(S));    // < 2 GiB (launch_jacobi_tb)
         // a first guess known to be all +0 (sources after step 0, the pressure) is never read: an
         // empty descriptor makes every load of it return 0
         a.bx = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(x), 0, batch.x_zero[blockIdx.z] ? 0u : field_bytes, 0x00020000);
         a.br = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(x0), 0, field_bytes, 0x00020000);
         a.bo = __builtin_amdgcn_make_buffer_rsrc(out, 0, field_bytes, 0x00020000);
-        a.row_bytes = (unsigned)(a.P * sizeof(S));
-        const unsigned col = (unsigned)((XOFF + 1 + 4 * (ptrdiff_t)k) * (ptrdiff_t)sizeof(S));
-        a.ld_off = a.ld_ok ? col : kBufOff;
+        a.row_bytes = (unsigned)((size_t)pitch * sizeof(S));
+        const unsigned col = (unsigned)((XOFF + 1 + NV * (ptrdiff_t)k) * (ptrdiff_t)sizeof(S));
+        a.ld_off = ld_ok ? col : kBufOff;
     }
     a.n = n;
-    const int kg = n >> 2;                               // ghost column n+1 = component cg of vector kg
-    a.cg = n & 3;
-    a.left_edge = (win == 0);                                                  // wave-uniform
-    a.right_edge = (kg >= win * VS - HL) && (kg < win * VS - HL + 64);         // wave-uniform
+    a.cg = n % NV;
     a.is_lg = (k == -1);
-    a.is_rg = (k == kg);
-    a.own = (lane >= HL) && (lane < 64 - HL);
-    a.st_int = a.own && k >= 0 && k < nvec;              // stores interior columns
-    a.st_rg_lane = a.is_rg && (a.own || k == nvec);      // stores ghost column n+1 (exactly one lane grid-wide)
-    a.last = n - (1 + 4 * k);                            // component of column n in this lane (if 0..3)
+    const bool is_rg = (k == kg);
+    const bool own = (lane >= HL) && (lane < 64 - HL);
+    const bool st_int = own && k >= 0 && k < nvec;       // stores interior columns
+    a.st_rg_lane = is_rg && (own || k == nvec);          // stores ghost column n+1 (exactly one lane grid-wide)
     a.m_lg = a.is_lg ? 0xFFFFFFFFu : 0u;
-    a.m_r0 = (a.is_rg && a.cg == 0) ? 0xFFFFFFFFu : 0u;
-    a.m_r1 = (a.is_rg && a.cg == 1) ? 0xFFFFFFFFu : 0u;
-    a.m_r2 = (a.is_rg && a.cg == 2) ? 0xFFFFFFFFu : 0u;
-    a.m_r3 = (a.is_rg && a.cg == 3) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) a.m_r[c] = (is_rg && a.cg == c) ? 0xFFFFFFFFu : 0u;
     // lanes that store: owners of interior columns (the ragged last vector included), the lane whose
-    // .w is ghost column 0 and the lane holding ghost column n+1; surplus components go to pads
-    a.st_off = (a.ld_ok && (a.st_int || a.is_lg || a.st_rg_lane)) ? a.ld_off : kBufOff;
+    // last component is ghost column 0 and the lane holding ghost column n+1; surplus components go to pads
+    a.st_off = (ld_ok && (st_int || a.is_lg || a.st_rg_lane)) ? a.ld_off : kBufOff;
     a.sx = (b == 1) ? 0x80000000u : 0u;
     a.sy = (b == 2) ? 0x80000000u : 0u;
     a.alpha = alpha;
     a.beta = beta;
     const int t0 = max(0, a.q_lo - T), t1 = a.q_hi - 1 + T;
-    a.t_ld = min(t1, n + 1);                             // last row that exists
     // a strip whose input rows [q_lo-T, q_hi-1+T] all exist never needs a regenerated ghost row
     const bool wall = (a.q_lo < T) || (a.q_hi - 1 + T > n + 1);      // wave-uniform
-    const bool edge = a.left_edge || a.right_edge;                   // wave-uniform
     if (edge) {
-        if (wall) tb_march<T, DIVMODE, true, true>(t0, t1, a);
-        else      tb_march<T, DIVMODE, true, false>(t0, t1, a);
+        if (wall) tb_march<T, DIVMODE, true, true, S, NV>(t0, t1, a);
+        else      tb_march<T, DIVMODE, true, false, S, NV>(t0, t1, a);
     } else {
-        if (wall) tb_march<T, DIVMODE, false, true>(t0, t1, a);
-        else      tb_march<T, DIVMODE, false, false>(t0, t1, a);
+        if (wall) tb_march<T, DIVMODE, false, true, S, NV>(t0, t1, a);
+        else      tb_march<T, DIVMODE, false, false, S, NV>(t0, t1, a);
     }
 }
 
@@ -955,35 +1112,55 @@ void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void
     }
 }
 
-// T in {8,4,2}; batch.count solves per launch.  divmode 0: beta; 1: beta = exact reciprocal;
-// 2: beta unused, yd = RN64(1/beta).
-void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, const TbBatch& batch, int pitch, int n, int row_lo,
+// T in {8,4,2} sweeps per launch, nv in {2,4} columns per lane; batch.count solves per launch.
+// divmode 0: beta; 2: beta unused, yd = RN64(1/beta); 4: beta = exact reciprocal of a power of two and alpha == 1.
+void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const TbBatch& batch, int pitch, int n, int row_lo,
                       int row_hi, int rb, int rb_edge)
 {
     const int rows = row_hi - row_lo;
     if (rows <= 0 || batch.count <= 0) return;
-    const int HL = (T + 3) / 4, VS = 64 - 2 * HL;
-    const unsigned nvec = (n + 3) / 4;
+    if (T == 16) nv = 2;
+    const int HL = (T + nv - 1) / nv, VS = 64 - 2 * HL;
+    const unsigned nvec = (n + nv - 1) / nv;
     rb_edge = rb_edge < 1 ? rb : (rb_edge > rb ? rb : rb_edge);
-    // grid.y covers the edge windows' (larger) strip count; interior windows leave the surplus blocks at once
-    const dim3 grid(cdiv(nvec, VS), cdiv(cdiv(rows, rb_edge), 4), batch.count), block(256);
-#define FLUID_TB1(TT, DD) \
-    FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_jacobi_tb<TT, DD, S>), grid, block, 0, s, batch, pitch, n, row_lo, row_hi, rb, rb_edge))
-#define FLUID_TB(TT)                     \
-    if (divmode == 2) FLUID_TB1(TT, 2);  \
-    else if (divmode == 1) FLUID_TB1(TT, 1); \
-    else FLUID_TB1(TT, 0)
-    if (T == 8) { FLUID_TB(8); }
-    else if (T == 4) { FLUID_TB(4); }
-    else { FLUID_TB(2); }
+    // edge windows: those whose 64 lanes include vector -1 (window 0) or vector kg = n / nv (the last one or two)
+    const int nwin = (int)cdiv(nvec, VS), kg = n / nv;
+    int first_right = nwin - 1;
+    while (first_right > 1 && kg < (first_right - 1) * VS - HL + 64) --first_right;
+    if (first_right < 1) first_right = 1;                // a single window is window 0
+    TbGrid g;
+    g.first_right = first_right;
+    g.inner_wins = first_right - 1;
+    g.edge_wins = 1 + (nwin - first_right);
+    g.inner_blocks = g.inner_wins * (int)cdiv(cdiv(rows, rb), 4);
+    g.edge_blocks = g.edge_wins * (int)cdiv(cdiv(rows, rb_edge), 4);
+    const dim3 grid(8 * cdiv(g.inner_blocks + g.edge_blocks, 8), 1, batch.count), block(256);
+#define FLUID_TB2(TT, DD, NN) \
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_jacobi_tb<TT, DD, NN, S>), grid, block, 0, s, batch, pitch, n, row_lo, row_hi, rb, rb_edge, g))
+#define FLUID_TB1(TT, DD)            \
+    if (nv == 2) FLUID_TB2(TT, DD, 2); \
+    else FLUID_TB2(TT, DD, 4)
+#define FLUID_TB(TT)                          \
+    if (divmode == 4) { FLUID_TB1(TT, 4); }      \
+    else if (divmode == 2) { FLUID_TB1(TT, 2); } \
+    else { FLUID_TB1(TT, 0); }
+    if (T == 16) {                                       // 2-column lanes only (4-column ones would need > 256 registers)
+        if (divmode == 4) { FLUID_TB2(16, 4, 2); }
+        else if (divmode == 2) { FLUID_TB2(16, 2, 2); }
+        else { FLUID_TB2(16, 0, 2); }
+    }
+    else if (T == 8) { FLUID_TB(8) }
+    else if (T == 4) { FLUID_TB(4) }
+    else { FLUID_TB(2) }
 #undef FLUID_TB
 #undef FLUID_TB1
+#undef FLUID_TB2
 }
 
 // mismatches of division mode `divmode` against a/beta over all 2^32 inputs are added to *bad
 void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, double yd, unsigned long long* bad)
 {
-    if (divmode == 1) hipLaunchKernelGGL((k_validate_div<1>), dim3(8192), dim3(256), 0, s, beta, arg, yd, bad);
+    if (divmode == 4) hipLaunchKernelGGL((k_validate_div<4>), dim3(8192), dim3(256), 0, s, beta, arg, yd, bad);
     else hipLaunchKernelGGL((k_validate_div<2>), dim3(8192), dim3(256), 0, s, beta, arg, yd, bad);
 }
 

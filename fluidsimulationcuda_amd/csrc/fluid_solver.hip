@@ -67,12 +67,12 @@ struct fluid_ctx {
     unsigned int* h_scalar = nullptr;     // pinned host mirror
     hipEvent_t scalar_ready = nullptr;    // recorded behind the scalar's device-to-host copy
     int variant = fluid::JACOBI_TB;
-    int tb_max_t = 8, tb_rows = 0, num_cu = 256;   // temporal blocking: sweeps/launch cap, rows/strip (0 = auto)
+    int tb_max_t = 16, tb_rows = 0, num_cu = 256;   // temporal blocking: sweeps/launch cap, rows/strip (0 = auto)
     long long tb_min_cells = 1500000;              // smaller slabs use single-sweep launches
-    int tb_blocks_per_cu = 2;                      // resident 256-thread blocks per CU the fused kernel is built for
+    int tb_nv = 2;                                 // columns per lane of the fused kernel (2: 4 waves/SIMD; 4: 2 waves/SIMD)
     int tb_edge_pct = 40;                          // strip height of the two edge windows, % of the others'
-    bool fast_div = true;                          // allow division modes 1/2 (each beta proven on the device first)
-    std::unordered_map<unsigned, int> div_mode;    // beta bits -> proven division mode
+    bool fast_div = true;                          // allow division modes 1/2/4 (each beta proven on the device first)
+    std::unordered_map<unsigned long long, int> div_mode;   // (wanted mode, beta bits) -> proven division mode
     // slab decomposition
     int rank = 0, nranks = 1, own0 = 1, own1 = 1, min_slab = 0, halo = 1;
     int reach[FLUID_NFIELDS] = {};            // see "row-slab bookkeeping" below
@@ -186,37 +186,41 @@ int timing_collect(fluid_ctx* c)
     } while (0)
 
 // Division mode for `beta` in the temporally blocked kernel: 0 = true division,
-// 1 = multiply by the exact reciprocal (beta a power of two), 2 = f64 reciprocal
-// multiply.  Modes 1 and 2 are only used after k_validate_div has compared them
+// 4 = multiply by the exact reciprocal (beta a power of two, alpha 1), 2 = f64 reciprocal
+// multiply.  Modes 2 and 4 are only used after k_validate_div has compared them
 // with a/beta for every one of the 2^32 float inputs on this device (a few ms,
 // once per beta and context).
-int division_mode(fluid_ctx* c, float beta, float* arg, double* yd)
+int division_mode(fluid_ctx* c, float beta, float alpha, float* arg, double* yd)
 {
     *arg = beta;
     *yd = 1.0 / (double)beta;
     if (!c->fast_div || !(beta > 0.f) || !std::isfinite(beta)) return 0;
-    unsigned bits;
-    std::memcpy(&bits, &beta, sizeof bits);
     int e2 = 0;
     const float rbeta = 1.0f / beta;
     const bool pow2 = std::frexp(beta, &e2) == 0.5f && std::isnormal(rbeta) && rbeta * beta == 1.0f;
-    auto it = c->div_mode.find(bits);
+    // mode 4 (pressure solve: alpha 1, beta 4): multiply by the exact reciprocal, and x * 1.0f is x so
+    // alpha is not applied at all; anything else: mode 2, the double-precision reciprocal
+    const int want = (pow2 && alpha == 1.0f) ? 4 : 2;
+    unsigned bits;
+    std::memcpy(&bits, &beta, sizeof bits);
+    const unsigned long long key = ((unsigned long long)want << 32) | bits;
+    auto it = c->div_mode.find(key);
     int mode;
     if (it != c->div_mode.end()) {
         mode = it->second;
     } else {
-        mode = pow2 ? 1 : 2;
+        mode = want;
         unsigned long long* bad = reinterpret_cast<unsigned long long*>(c->d_scalar) + 1;   // 8-byte slot of the 256-B block
         unsigned long long* hbad = reinterpret_cast<unsigned long long*>(c->h_scalar) + 1;
         if (hipMemsetAsync(bad, 0, sizeof *bad, c->stream) != hipSuccess) return 0;
-        fluid::launch_validate_div(c->stream, mode, beta, pow2 ? rbeta : beta, *yd, bad);
+        fluid::launch_validate_div(c->stream, mode, beta, mode == 4 ? rbeta : beta, *yd, bad);
         if (hipMemcpyAsync(hbad, bad, sizeof *bad, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess)
             return 0;
         if (*hbad != 0) mode = 0;                  // never observed; keeps the bit-exact contract regardless
-        c->div_mode.emplace(bits, mode);
+        c->div_mode.emplace(key, mode);
     }
-    if (mode == 1) *arg = rbeta;
+    if (mode == 4) *arg = rbeta;
     return mode;
 }
 
@@ -353,7 +357,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         nxt[k] = kScratch[k];
         div_arg[k] = sv[k].beta;
         yd[k] = 0.0;
-        divmode[k] = c->variant == fluid::JACOBI_TB ? division_mode(c, sv[k].beta, &div_arg[k], &yd[k]) : 0;
+        divmode[k] = c->variant == fluid::JACOBI_TB ? division_mode(c, sv[k].beta, sv[k].alpha, &div_arg[k], &yd[k]) : 0;
         same_mode = same_mode && divmode[k] == divmode[0];
     }
     auto reach_now = [&]() {
@@ -378,6 +382,9 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
             // the fused kernel addresses a field through 32-bit buffer offsets: fields of 2 GiB and more
             // (beyond ~23000^2 in fp32) take single-sweep launches
             if (c->variant != fluid::JACOBI_TB || small || c->field_bytes >= 0x7F000000ull) return 1;
+            // 16 sweeps per launch exist for 2-column lanes and fp32 storage (fp16 results depend on the
+            // launch schedule, which stays the 8-sweep one)
+            if (room >= 16 && c->tb_max_t >= 16 && c->tb_nv == 2 && !canonical) return 16;
             return (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
         };
         const int wantT = canonical ? pick(remaining) : 1;     // slabs with fp16 storage keep halo >= 8 (fluid_create_ex)
@@ -422,27 +429,30 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 const int edge_pct = c->tb_edge_pct > 0 ? c->tb_edge_pct : 100;
                 auto edge_rows = [&](int r) { return std::max(2 * T, r * edge_pct / 100); };
                 if (rb <= 0) {
-                    // auto (tools/tb_sweep.py on MI355X): the kernel is latency-bound per wave, so it wants
-                    // every block resident at once -- 2 blocks per CU at T=8 (~200 VGPRs), 3 below -- and
-                    // then the tallest strips that still allow (each strip pays 2T rows of pipeline fill).
-                    // Smallest strip height whose non-empty blocks fit 92 % of one round; grids too large for
-                    // one round stop at 80 rows (160 for a batch), past which more strips win again.
-                    const int HL = (T + 3) / 4, VS = 64 - 2 * HL;
-                    const long long windows = ((c->n + 3) / 4 + VS - 1) / VS;
-                    const long long room = (long long)c->num_cu * (T >= 8 ? c->tb_blocks_per_cu : 3) * 92 / 100;
+                    // auto (tools/tb_sweep.py on MI355X): the kernel hides its latencies only behind other
+                    // waves, so it wants every block resident at once -- a 256-thread block is one wave per
+                    // SIMD, tb_waves_per_simd blocks fit a CU -- and then the tallest strips that still
+                    // allow (each strip pays 2T rows of pipeline fill).  Smallest strip height whose
+                    // non-empty blocks fit 92 % of one round; grids too large for one round stop at 80
+                    // rows (160 for a batch; 192 at T = 16), past which more strips win again.
+                    const int nv = c->tb_nv;
+                    const int HL = (T + nv - 1) / nv, VS = 64 - 2 * HL;
+                    const long long windows = ((c->n + nv - 1) / nv + VS - 1) / VS;
+                    const int resident = nv == 2 ? (T >= 16 ? 2 : 4) : (T >= 8 ? 2 : 3);
+                    const long long room = (long long)c->num_cu * resident * 92 / 100;
                     const long long rows_n = hi - lo;
                     auto blocks = [&](int r) {
                         const long long si = (rows_n + r - 1) / r, se = (rows_n + edge_rows(r) - 1) / edge_rows(r);
                         const long long inner = windows > 2 ? windows - 2 : 0, outer = windows - inner;
                         return (inner * ((si + 3) / 4) + outer * ((se + 3) / 4)) * m;
                     };
-                    const int cap = (T >= 8 ? 80 : 96) * (m > 1 ? 2 : 1);
+                    const int cap = T >= 16 ? 192 : (T >= 8 ? 80 : 96) * (m > 1 ? 2 : 1);
                     rb = 2 * T;
                     while (rb < cap && blocks(rb) > room) rb += 2;
                 }
                 // edge windows (ghost columns) cost ~1.6x per row: shorter strips there keep the launch balanced
                 const int rb_edge = std::min(rb, edge_rows(rb));
-                fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], bt, c->pitch, c->n, lo, hi, rb, rb_edge);
+                fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], c->tb_nv, bt, c->pitch, c->n, lo, hi, rb, rb_edge);
                 first = last;
             }
         }
@@ -949,7 +959,7 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
     TRY(check_ctx(c));
     switch (key) {
     case FLUID_PARAM_TB_MAX_SWEEPS:
-        if (value != 8 && value != 4 && value != 2) return fail(FLUID_E_INVALID, "TB_MAX_SWEEPS must be 8, 4 or 2");
+        if (value != 16 && value != 8 && value != 4 && value != 2) return fail(FLUID_E_INVALID, "TB_MAX_SWEEPS must be 16, 8, 4 or 2");
         c->tb_max_t = value;
         return FLUID_OK;
     case FLUID_PARAM_TB_ROWS:
@@ -966,6 +976,10 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
         return FLUID_OK;
     case FLUID_PARAM_TB_FAST_DIVISION:
         c->fast_div = value != 0;
+        return FLUID_OK;
+    case FLUID_PARAM_TB_LANE_COLUMNS:
+        if (value != 2 && value != 4) return fail(FLUID_E_INVALID, "TB_LANE_COLUMNS must be 2 or 4");
+        c->tb_nv = value;
         return FLUID_OK;
     case FLUID_PARAM_HALO:
         if (value < 1) return fail(FLUID_E_INVALID, "HALO must be >= 1");

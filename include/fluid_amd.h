@@ -50,14 +50,17 @@ enum { FLUID_JACOBI_STREAM = 0, FLUID_JACOBI_LDS = 1, FLUID_JACOBI_NAIVE = 2, FL
 
 /* Tuning knobs for fluid_set_param(); none of them changes results. */
 enum {
-    FLUID_PARAM_TB_MAX_SWEEPS = 0, /* sweeps fused per launch by FLUID_JACOBI_TB: 8 (default), 4 or 2 */
+    FLUID_PARAM_TB_MAX_SWEEPS = 0, /* most sweeps fused per launch by FLUID_JACOBI_TB: 16 (default), 8, 4 or 2 */
     FLUID_PARAM_TB_ROWS = 1,       /* output rows per wave strip of FLUID_JACOBI_TB; 0 = auto          */
     FLUID_PARAM_HALO = 2,          /* multi-GPU ghost-zone depth (clamped to slab height - 1)          */
     FLUID_PARAM_TB_FAST_DIVISION = 3 /* 1 (default): FLUID_JACOBI_TB may replace x/beta by an exactly equivalent
-                                      reciprocal multiply, after proving the equivalence for that beta on all
-                                      2^32 float inputs on the device; 0: always divide                  */
+                                      reciprocal multiply (in double; in float when beta is a power of two),
+                                      after proving the equivalence for that beta on all 2^32 float inputs
+                                      on the device; 0: always divide                                    */
     ,FLUID_PARAM_TB_EDGE_ROWS_PCT = 5 /* strip height of the two windows that carry the ghost columns, in % of
                                       the interior windows' (default 40; 0 = same): load balance only  */
+    ,FLUID_PARAM_TB_LANE_COLUMNS = 6 /* columns per lane of FLUID_JACOBI_TB: 2 (default; thin waves, 4 per SIMD)
+                                      or 4 (2 per SIMD): speed only                                      */
     ,FLUID_PARAM_TB_MIN_CELLS = 4  /* FLUID_JACOBI_TB fuses sweeps only on slabs of at least this many cells
                                       (default 1 500 000); smaller ones run one-thread-per-cell sweeps   */
 };

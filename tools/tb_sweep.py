@@ -19,12 +19,15 @@ x = rng.random((n + 2, n + 2), dtype=np.float32)
 with F.FluidSolver(n, jacobi=capi.JACOBI_TB) as s:
     s.upload(u=x, v=x)
     a, b = F.coefficients(n, 0.016, 0.0025)
+    if os.environ.get('TB_NV'):
+        s.set_param(capi.PARAM_TB_LANE_COLUMNS, int(os.environ['TB_NV']))
+    nv = int(os.environ.get('TB_NV', '2'))
     if os.environ.get('TB_EDGE'):
         s.set_param(capi.PARAM_TB_EDGE_ROWS_PCT, int(os.environ['TB_EDGE']))
     for T in Ts:
         s.set_param(capi.PARAM_TB_MAX_SWEEPS, T)
-        HL = (T + 3) // 4
-        nwin = -(-((n + 3) // 4) // (64 - 2 * HL))
+        HL = (T + nv - 1) // nv
+        nwin = -(-((n + nv - 1) // nv) // (64 - 2 * HL))
         for rows in ([int(r) for r in os.environ['TB_ROWS'].split(',')] if os.environ.get('TB_ROWS') else list(range(8, 41, 2)) + [44, 48, 56, 64, 96, 128]):
             s.set_param(capi.PARAM_TB_ROWS, rows)
             out = []
