@@ -27,6 +27,7 @@ struct TbBatch {
     double yd[3];                // RN64(1/beta) for division mode 2
     int b[3];
     int x_zero[3];               // first guess known to be all +0: never read
+    float x0_inc[3];             // added to every x0 value as it is loaded (-0.0f: nothing pending)
     int count;
 };
 
@@ -39,6 +40,8 @@ void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const T
 void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, double yd, unsigned long long* bad);
 void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u, const void* v, int pitch, int n,
                    int row_lo, int row_hi, float dt0, int b);
+void launch_advect2(hipStream_t s, int st, void* da, const void* d0a, int ba, void* db, const void* d0b, int bb, const void* u,
+                    const void* v, int pitch, int n, int row_lo, int row_hi, float dt0);
 void launch_divergence(hipStream_t s, int st, const void* u, const void* v, void* p, void* div, int pitch, int n,
                        int row_lo, int row_hi, float h, int write_p);
 void launch_subtract_gradient(hipStream_t s, int st, void* u, void* v, const void* p, int pitch, int n, int row_lo,

@@ -513,6 +513,7 @@ struct TbArgs {
     float alpha, beta;
     double yd;            // DIVMODE 2: 1/beta rounded to double
     unsigned sx, sy;      // sign masks: flip across vertical / horizontal walls
+    float x0_inc;         // pending add_source increment of the right-hand side (-0.0f: none)
     bool st_rg_lane, is_lg;
 };
 
@@ -692,6 +693,12 @@ __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[
     __builtin_amdgcn_sched_barrier(0);                   // (and not hoisted into the previous step either)
     W[0][FR] = take<NV>(PX[PH]);
     Q[0] = take<NV>(PQ[PH]);
+#pragma unroll
+    for (int p = 0; p < NV; p += 2) {                    // x0 + dt*0 where an add_source was deferred, else x0 + (-0) = x0
+        const v2f q = (v2f){Q[0].c[p], Q[0].c[p + 1]} + a.x0_inc;
+        Q[0].c[p] = q.x;
+        Q[0].c[p + 1] = q.y;
+    }
     {   // refill the slot with row t+3: three steps of arithmetic cover the memory latency.  Rows past
         // the field's end and lanes past its width fall outside the buffer and read as 0.
         const unsigned off = a.ld_off + (unsigned)(t + 3) * a.row_bytes;
@@ -849,6 +856,7 @@ __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbB
     const int rbw = edge ? rb_edge : rb;
     TbArgs<S, NV> a;
     a.yd = yd;
+    a.x0_inc = batch.x0_inc[blockIdx.z];
     a.q_lo = row_lo + strip * rbw;                       // this wave's output rows [q_lo, q_hi)
     if (a.q_lo >= row_hi) return;                        // wave-uniform
     a.q_hi = min(a.q_lo + rbw, row_hi);
@@ -929,6 +937,48 @@ __global__ __launch_bounds__(256) void k_advect(S* __restrict__ d, const S* __re
     const float val = s0 * a + s1 * e;
     st1(d + c, val);
     emit_ghosts(d, P, n, b, j, i, val);
+}
+
+// Two advections along the same velocity field in one pass (vel_step advects u and v, both along
+// (u0, v0), FluidSequential.c:213-214): the velocity is read and the back-trace computed once, and
+// the eight taps of the two sources sit at the same offsets.  Per field the arithmetic is k_advect's.
+template <typename S>
+__global__ __launch_bounds__(256) void k_advect2(S* __restrict__ da, const S* __restrict__ d0a, int ba, S* __restrict__ db,
+                                                 const S* __restrict__ d0b, int bb, const S* __restrict__ u,
+                                                 const S* __restrict__ v, int pitch, int n, int row_lo, int row_hi, float dt0)
+{
+    const int j = 1 + blockIdx.x * 256 + threadIdx.x;
+    const int i = row_lo + blockIdx.y;
+    if (j > n || i >= row_hi) return;
+    const size_t P = (size_t)pitch;
+    const size_t c = (size_t)i * P + XOFF + j;
+    float px = (float)j - dt0 * ld1(u + c);
+    float py = (float)i - dt0 * ld1(v + c);
+    const float hi = (float)n + 0.5f;
+    if (px < 0.5f) px = 0.5f;
+    if (px > hi) px = hi;
+    if (py < 0.5f) py = 0.5f;
+    if (py > hi) py = hi;
+    const int j0 = (int)px, i0 = (int)py;
+    const float s1 = px - (float)j0, s0 = 1.0f - s1;
+    const float t1 = py - (float)i0, t0 = 1.0f - t1;
+    const size_t o = (size_t)i0 * P + XOFF + j0;
+    {
+        const S* q = d0a + o;
+        const float a = t0 * ld1(q) + t1 * ld1(q + P);
+        const float e = t0 * ld1(q + 1) + t1 * ld1(q + P + 1);
+        const float val = s0 * a + s1 * e;
+        st1(da + c, val);
+        emit_ghosts(da, P, n, ba, j, i, val);
+    }
+    {
+        const S* q = d0b + o;
+        const float a = t0 * ld1(q) + t1 * ld1(q + P);
+        const float e = t0 * ld1(q + 1) + t1 * ld1(q + P + 1);
+        const float val = s0 * a + s1 * e;
+        st1(db + c, val);
+        emit_ghosts(db, P, n, bb, j, i, val);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1170,6 +1220,15 @@ void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u
     if (row_hi <= row_lo) return;
     FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_advect<S>, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s, (S*)d,
                                             (const S*)d0, (const S*)u, (const S*)v, pitch, n, row_lo, row_hi, dt0, b));
+}
+
+void launch_advect2(hipStream_t s, int st, void* da, const void* d0a, int ba, void* db, const void* d0b, int bb, const void* u,
+                    const void* v, int pitch, int n, int row_lo, int row_hi, float dt0)
+{
+    if (row_hi <= row_lo) return;
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_advect2<S>, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s, (S*)da,
+                                            (const S*)d0a, ba, (S*)db, (const S*)d0b, bb, (const S*)u, (const S*)v, pitch, n,
+                                            row_lo, row_hi, dt0));
 }
 
 void launch_divergence(hipStream_t s, int st, const void* u, const void* v, void* p, void* div, int pitch, int n,

@@ -69,6 +69,8 @@ struct fluid_ctx {
     int variant = fluid::JACOBI_TB;
     int tb_max_t = 16, tb_rows = 0, num_cu = 256;   // temporal blocking: sweeps/launch cap, rows/strip (0 = auto)
     long long tb_min_cells = 1500000;              // smaller slabs use single-sweep launches
+    bool defer_zero_source = true;                 // see settle()
+    bool in_halo_exchange = false;
     int tb_nv = 2;                                 // columns per lane of the fused kernel (2: 4 waves/SIMD; 4: 2 waves/SIMD)
     int tb_edge_pct = 40;                          // strip height of the two edge windows, % of the others'
     bool fast_div = true;                          // allow division modes 1/2/4 (each beta proven on the device first)
@@ -77,6 +79,8 @@ struct fluid_ctx {
     int rank = 0, nranks = 1, own0 = 1, own1 = 1, min_slab = 0, halo = 1;
     int reach[FLUID_NFIELDS] = {};            // see "row-slab bookkeeping" below
     bool zero[FLUID_NFIELDS] = {};            // field is all +0 by definition; its memory is NOT (yet) zeroed
+    bool pend[FLUID_NFIELDS] = {};            // field owes itself `+ pend_inc[f]` in every cell (deferred add_source of a zero source)
+    float pend_inc[FLUID_NFIELDS] = {};
     fluid_exchange_fn xchg = nullptr;
     void* xchg_user = nullptr;
     // timing
@@ -234,7 +238,11 @@ constexpr int kEverywhere = 1 << 28;
 
 int exchange_cap(const fluid_ctx* c) { return c->min_slab - 1; }     // rows a neighbour can always supply
 
-void wrote(fluid_ctx* c, int f, int reach) { c->reach[f] = c->nranks > 1 ? reach : kEverywhere; }
+void wrote(fluid_ctx* c, int f, int reach)
+{
+    c->reach[f] = c->nranks > 1 ? reach : kEverywhere;
+    c->pend[f] = false;                        // overwritten: whatever the old contents still owed is moot
+}
 
 int need_list(fluid_ctx* c, const std::vector<int>& fields, int reach)
 {
@@ -247,7 +255,9 @@ int need_list(fluid_ctx* c, const std::vector<int>& fields, int reach)
     if (!c->xchg) return fail(FLUID_E_COMM, "multi-GPU context without an exchange callback");
     std::sort(ids.begin(), ids.end());
     ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    c->in_halo_exchange = true;            // rows travel as they are in memory; a pending increment stays pending on every rank alike
     const int rc = c->xchg(c->xchg_user, FLUID_XCHG_HALO, ids.data(), (int)ids.size(), reach, nullptr);
+    c->in_halo_exchange = false;
     if (rc != 0) return fail(FLUID_E_COMM, "halo exchange failed (rc %d)", rc);
     for (int f : ids) c->reach[f] = reach;
     return FLUID_OK;
@@ -272,12 +282,37 @@ void rows(const fluid_ctx* c, int reach, int* lo, int* hi)
 // (add_source adds the constant dt*0, the fused Jacobi kernel reads nothing, the
 // divergence kernel skips its p stores) and everything else materialises the
 // zeros first.
-int materialize(fluid_ctx* c, int f)
+// add_source with a source that is zero by definition adds the constant dt*0 to every cell: it
+// changes nothing but the sign of -0 (and NaN/inf rules for a non-finite dt), yet costs a read and a
+// write of the whole field.  With the fused Jacobi kernel the increment stays PENDING instead: the
+// solve that consumes the field as its right-hand side adds it to each row as it loads it, any other
+// reader settles it with the real kernel first (here), and a writer that replaces the field drops it.
+int settle(fluid_ctx* c, int f)
+{
+    if (!c->pend[f]) return FLUID_OK;
+    const int reach = c->nranks > 1 ? std::min(c->reach[f], exchange_cap(c)) : 0;
+    int lo, hi;
+    rows(c, reach, &lo, &hi);
+    if (lo == 1) lo = 0;
+    if (hi == c->n + 1) hi = c->n + 2;
+    const float inc = c->pend_inc[f];
+    c->pend[f] = false;
+    TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->st, c->f[f], nullptr, c->pitch, lo, hi, inc));
+    return FLUID_OK;
+}
+
+int materialize_zero(fluid_ctx* c, int f)
 {
     if (!c->zero[f]) return FLUID_OK;
     HIP_TRY(hipMemsetAsync(c->f[f], 0, c->field_bytes, c->stream));
     c->zero[f] = false;
     return FLUID_OK;
+}
+
+int materialize(fluid_ctx* c, int f)
+{
+    TRY(materialize_zero(c, f));
+    return settle(c, f);
 }
 
 int materialize(fluid_ctx* c, std::initializer_list<int> fs)
@@ -289,6 +324,7 @@ int materialize(fluid_ctx* c, std::initializer_list<int> fs)
 void mark_zero(fluid_ctx* c, int f)
 {
     c->zero[f] = true;
+    c->pend[f] = false;
     c->reach[f] = kEverywhere;
 }
 
@@ -305,6 +341,11 @@ int op_add_source(fluid_ctx* c, int x, int s, float dt)
     if (c->zero[s]) {
         volatile float z = 0.0f;
         const float inc = dt * z;          // the reference's dt * s[i] with s[i] = +0 (sign and NaN rules included)
+        if (c->variant == fluid::JACOBI_TB && c->defer_zero_source) {
+            c->pend[x] = true;             // (x was settled just above: one pending increment at a time)
+            c->pend_inc[x] = inc;
+            return FLUID_OK;               // reach[x] unchanged: nothing was written
+        }
         TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->st, c->f[x], nullptr, c->pitch, lo, hi, inc));
     } else {
         TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->st, c->f[x], c->f[s], c->pitch, lo, hi, dt));
@@ -344,7 +385,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 return fail(FLUID_E_INVALID, "diffuse: the solves of a batch must not share fields");
     }
     if (iters == 0) return FLUID_OK;
-    for (int k = 0; k < count; ++k) TRY(materialize(c, sv[k].x0));
+    for (int k = 0; k < count; ++k) TRY(materialize_zero(c, sv[k].x0));     // a pending increment rides along (TbBatch::x0_inc)
     hipEvent_t stop;
     TRY(timing_begin(c, FLUID_TIME_DIFFUSION, &stop));
     const bool multi = c->nranks > 1;
@@ -404,6 +445,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         if (T == 1) {
             const int v = c->variant == fluid::JACOBI_TB ? (small ? fluid::JACOBI_NAIVE : fluid::JACOBI_STREAM) : c->variant;
             for (int j = 0; j < count; ++j) TRY(materialize(c, cur[j]));      // single-sweep kernels read x
+            for (int j = 0; j < count; ++j) TRY(settle(c, sv[j].x0));         // ... and x0 as it is in memory
             for (int j = 0; j < count; ++j)
                 fluid::launch_jacobi(c->stream, c->st, v, c->f[cur[j]], c->f[sv[j].x0], c->f[nxt[j]], c->pitch, c->n, lo, hi,
                                      sv[j].alpha, sv[j].beta, sv[j].b);
@@ -422,6 +464,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                     bt.yd[m] = yd[j];
                     bt.b[m] = sv[j].b;
                     bt.x_zero[m] = c->zero[cur[j]] ? 1 : 0;
+                    bt.x0_inc[m] = c->pend[sv[j].x0] ? c->pend_inc[sv[j].x0] : -0.0f;     // x + (-0) is x for every x
                     ++m;
                 }
                 bt.count = m;
@@ -470,6 +513,8 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         if (cur[j] != sv[j].x) {
             std::swap(c->f[sv[j].x], c->f[kScratch[j]]);
             std::swap(c->reach[sv[j].x], c->reach[kScratch[j]]);
+            std::swap(c->pend[sv[j].x], c->pend[kScratch[j]]);
+            std::swap(c->pend_inc[sv[j].x], c->pend_inc[kScratch[j]]);
         }
         wrote(c, kScratch[j], 0);
     }
@@ -532,6 +577,24 @@ int op_advect(fluid_ctx* c, int b, int d, int d0, int u, int v, float dt)
     TIMED(c, FLUID_TIME_ADVECTION,
           fluid::launch_advect(c->stream, c->st, c->f[d], c->f[d0], c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, dt0, b));
     wrote(c, d, 0);
+    return FLUID_OK;
+}
+
+// two advections along the same velocity (u, v) in one launch; results identical to two op_advect calls
+int op_advect2(fluid_ctx* c, int ba, int da, int d0a, int bb, int db, int d0b, int u, int v, float dt)
+{
+    for (int d : {da, db})
+        if (d == d0a || d == d0b || d == u || d == v) return fail(FLUID_E_INVALID, "advect: output must not alias an input");
+    if (da == db) return fail(FLUID_E_INVALID, "advect: outputs must be distinct");
+    const float dt0 = dt * (float)c->n;
+    TRY(materialize(c, {d0a, d0b, u, v}));
+    c->zero[da] = false;
+    c->zero[db] = false;
+    TIMED(c, FLUID_TIME_ADVECTION,
+          fluid::launch_advect2(c->stream, c->st, c->f[da], c->f[d0a], ba, c->f[db], c->f[d0b], bb, c->f[u], c->f[v], c->pitch,
+                                c->n, c->own0, c->own1, dt0));
+    wrote(c, da, 0);
+    wrote(c, db, 0);
     return FLUID_OK;
 }
 
@@ -612,8 +675,7 @@ int vel_step(fluid_ctx* c, float dt, float visc, int iters)
     TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
     const float dt0 = dt * (float)c->n;
     TRY(advect_prepare(c, {U0, V0}, U0, V0, dt0));
-    TRY(op_advect(c, 1, U, U0, U0, V0, dt));
-    TRY(op_advect(c, 2, V, V0, U0, V0, dt));
+    TRY(op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt));
     return project(c, U, V, /*p=*/U0, /*div=*/V0, iters);
 }
 
@@ -650,8 +712,7 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
     if (c->nranks == 1) {
         TRY(op_diffuse_batch(c, all, 3, iters));
         TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
-        TRY(op_advect(c, 1, U, U0, U0, V0, dt));
-        TRY(op_advect(c, 2, V, V0, U0, V0, dt));
+        TRY(op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt));
         TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters));
         return op_advect(c, 0, D, D0, U, V, dt);
     }
@@ -668,8 +729,7 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
     TRY(vmax_begin(c, U0, V0));
     if (fill1 > 0) TRY(op_diffuse_batch(c, all + 2, 1, fill1));
     TRY(advect_halo(c, {U0, V0}, dt0));
-    TRY(op_advect(c, 1, U, U0, U0, V0, dt));
-    TRY(op_advect(c, 2, V, V0, U0, V0, dt));
+    TRY(op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt));
     TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters));
     TRY(vmax_begin(c, U, V));
     if (fill2 > 0) TRY(op_diffuse_batch(c, all + 2, 1, fill2));
@@ -889,7 +949,8 @@ int fluid_field_ptr(fluid_ctx* c, int field, void** dev_ptr)
     TRY(check_ctx(c));
     TRY(check_fields(c, {field}));
     if (!dev_ptr) return fail(FLUID_E_INVALID, "null pointer");
-    TRY(materialize(c, field));            // whoever asks for the address may read the memory
+    if (c->in_halo_exchange) TRY(materialize_zero(c, field));
+    else TRY(materialize(c, field));       // whoever asks for the address may read the memory
     *dev_ptr = c->f[field];
     return FLUID_OK;
 }

@@ -203,19 +203,22 @@ def test_reductions(F, oracle):
 
 
 # ---- temporally blocked kernel: window / strip / wall edge cases ---------------
-# windows are 64 float4 lanes overlapping by ceil(T/4) per side: 240 owned
-# columns at T=8, 248 at T=4, 248 at T=2 -> sizes straddling those multiples;
-# strips of `rows` output rows overlap by T rows: tiny, ragged and huge strips.
-TB_SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 14, 61, 64, 239, 240, 241, 247, 248, 249, 255, 256, 257, 480, 481, 1022]
+# A window is one wave: 64 lanes of 2 or 4 columns, overlapping its neighbours by ceil(T/cols) lanes
+# per side.  Owned columns per window: 4-column lanes 240 (T=8), 248 (T=4, 2); 2-column lanes 96
+# (T=16), 112 (T=8), 120 (T=4), 124 (T=2) -> sizes straddling those multiples; strips of `rows`
+# output rows overlap by T rows: tiny, ragged and huge strips.
+TB_SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 14, 61, 64, 95, 96, 97, 111, 112, 113, 119, 120, 121, 123, 124, 125, 191, 192, 193,
+            223, 224, 225, 239, 240, 241, 247, 248, 249, 255, 256, 257, 480, 481, 1022]
 
 
-@pytest.mark.parametrize("max_t", [8, 4, 2])
+@pytest.mark.parametrize("lane_cols,max_t", [(2, 16), (2, 8), (2, 4), (2, 2), (4, 8), (4, 4), (4, 2)])
 @pytest.mark.parametrize("n", TB_SIZES)
-def test_temporal_blocking_matches_oracle(F, oracle, n, max_t):
+def test_temporal_blocking_matches_oracle(F, oracle, n, lane_cols, max_t):
     from fluidsimulationcuda_amd import capi
     rng = np.random.default_rng(500 + n)
     with F.FluidSolver(n, jacobi=capi.JACOBI_TB) as s:
         s.set_param(capi.PARAM_TB_MIN_CELLS, 0)              # fuse sweeps even on these small grids
+        s.set_param(capi.PARAM_TB_LANE_COLUMNS, lane_cols)
         s.set_param(capi.PARAM_TB_MAX_SWEEPS, max_t)
         for rows in (0, 1, 3, 16, 5000):
             s.set_param(capi.PARAM_TB_ROWS, rows)
@@ -227,7 +230,7 @@ def test_temporal_blocking_matches_oracle(F, oracle, n, max_t):
                 want = x.copy()
                 oracle.diffuse(b, want, x0, alpha, beta, iters)
                 assert_bit_equal(s.download("u"), want,
-                                 "TB n=%d maxT=%d rows=%d b=%d iters=%d" % (n, max_t, rows, b, iters))
+                                 "TB n=%d cols=%d maxT=%d rows=%d b=%d iters=%d" % (n, lane_cols, max_t, rows, b, iters))
                 assert_bit_equal(s.download("v"), x0, "x0 untouched")
 
 
