@@ -392,7 +392,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
     int cur[3], nxt[3], divmode[3];
     float div_arg[3];
     double yd[3];
-    bool same_mode = true;
+    bool same_mode = true, all_mode4 = true;
     for (int k = 0; k < count; ++k) {
         cur[k] = sv[k].x;
         nxt[k] = kScratch[k];
@@ -400,6 +400,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         yd[k] = 0.0;
         divmode[k] = c->variant == fluid::JACOBI_TB ? division_mode(c, sv[k].beta, sv[k].alpha, &div_arg[k], &yd[k]) : 0;
         same_mode = same_mode && divmode[k] == divmode[0];
+        all_mode4 = all_mode4 && divmode[k] == 4;
     }
     auto reach_now = [&]() {
         int r = kEverywhere;
@@ -425,7 +426,11 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
             if (c->variant != fluid::JACOBI_TB || small || c->field_bytes >= 0x7F000000ull) return 1;
             // 16 sweeps per launch exist for 2-column lanes and fp32 storage (fp16 results depend on the
             // launch schedule, which stays the 8-sweep one)
-            if (room >= 16 && c->tb_max_t >= 16 && c->tb_nv == 2 && !canonical) return 16;
+            // -- where they pay: the pressure form (a packed multiply per pair) is bound by memory at every
+            // size; the general form (a double-precision multiply per cell) is bound by arithmetic, which
+            // deeper blocking only adds to, until the fields outgrow the 256 MB Infinity Cache
+            if (room >= 16 && c->tb_max_t >= 16 && c->tb_nv == 2 && !canonical && (all_mode4 || c->field_bytes > (96ull << 20)))
+                return 16;
             return (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
         };
         const int wantT = canonical ? pick(remaining) : 1;     // slabs with fp16 storage keep halo >= 8 (fluid_create_ex)
