@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--grid", type=int, default=0, help="grid width W=N+2 (default 4096 on 1 GPU, 8192 on several)")
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--variant", type=int, default=3, help="Jacobi kernel: 0 stream, 1 LDS-tiled, 2 naive, 3 temporally blocked")
-    ap.add_argument("--tb-sweeps", type=int, default=0, help="temporal blocking: sweeps per launch (8, 4, 2; 0 = default)")
+    ap.add_argument("--tb-sweeps", type=int, default=0, help="temporal blocking: most sweeps per launch (16, 8, 4, 2; 0 = default)")
     ap.add_argument("--tb-rows", type=int, default=0, help="temporal blocking: rows per wave strip (0 = auto)")
     ap.add_argument("--halo", type=int, default=0, help="multi-GPU ghost-zone depth (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -56,7 +56,8 @@ def parse():
 
 def measure(solver, dist, world, steps, warmup, iters, cells):
     """W untimed steps, then exactly K timed steps between barrier+synchronize
-    pairs; returns (max-over-ranks seconds, max-over-ranks Jacobi ms, sweeps)."""
+    pairs; returns (max-over-ranks seconds, max-over-ranks Jacobi ms, sweeps, Jacobi launches,
+    launches counted once per field swept)."""
     import torch
     solver.step(1, use_sources=True, iters=iters)          # z == 0 consumes the synthetic sources
     for _ in range(max(warmup - 1, 0)):
@@ -80,14 +81,14 @@ def measure(solver, dist, world, steps, warmup, iters, cells):
                            device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(buf, op=dist.ReduceOp.MAX)
         elapsed, jac_ms = float(buf[0]), float(buf[1])
-    return elapsed, jac_ms, sweeps
+    return elapsed, jac_ms, sweeps, t["jacobi_launches"], t["jacobi_field_launches"]
 
 
 def pmc_traffic(kernel, grid):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
-    PMC summary (profiles/r*_<grid>_pmc.json, written by tools/summarize_profiles.py
-    from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this same command,
-    gfx950 x2 read correction applied).  None when no summary matches."""
+    """Mean HBM bytes per launch of the dominant kernel (all its instantiations, weighted by how often
+    each ran) from the committed rocprofv3 PMC summary (profiles/r*_<grid>_pmc.json, written by
+    tools/summarize_profiles.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this same
+    command, gfx950 x2 read correction applied).  The newest summary wins; None when none matches."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%d_pmc.json" % grid))):
@@ -95,16 +96,14 @@ def pmc_traffic(kernel, grid):
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
+        tot = cnt = 0.0
         for name, v in d.items():
-            if not v.get("hbm_bytes_per_launch"):
+            if name.split("<")[0] != kernel or not v.get("hbm_bytes_per_launch"):
                 continue
-            if name.split("<")[0] != kernel:
-                continue
-            # fused kernel: price the single-field launch (pressure solve, division mode 1);
-            # the batched diffusion launch moves three fields
-            if kernel == "k_jacobi_tb" and ", 1, float>" not in name:
-                continue
-            best = (v["hbm_bytes_per_launch"], os.path.basename(f))
+            tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
+            cnt += v["launches_sampled"]
+        if cnt:
+            best = (tot / cnt, os.path.basename(f))
     return best
 
 
@@ -210,19 +209,16 @@ def main():
                     sys.exit("rank %d: %s differs between %d slabs and one context" % (rank, k, world))
         if rank == 0:
             print("check ok: %d slabs bit-identical to one context at %dx%d" % (world, grid, grid), file=sys.stderr)
-    (elapsed, jac_ms, sweeps), fields, calls = run(n, a.steps, a.warmup)
+    (elapsed, jac_ms, sweeps, launches, field_launches), fields, calls = run(n, a.steps, a.warmup)
     ms_step = elapsed * 1e3 / a.steps
     t_sweep = jac_ms * 1e-3 / max(sweeps, 1)
     mcells = cells / t_sweep / 1e6
     bpc = BYTES_PER_CELL_SWEEP // (2 if a.dtype == "f16" else 1)
     achieved = bpc * cells / t_sweep / 1e9
-    fused = 1
-    if a.variant == 3:
-        fused = a.tb_sweeps or 8
-        while a.iters % fused:
-            fused //= 2
-    kernel_name = ("k_jacobi_tb<%d> (%d sweeps + set_bnd per launch)" % (fused, fused)) if a.variant == 3 else \
-        "k_jacobi_%s (one sweep + fused set_bnd)" % KERNELS[a.variant]
+    launches = max(launches, 1)
+    per_launch = sweeps / launches                       # field-sweeps per launch (a batched launch sweeps 3 fields)
+    kernel_name = ("k_jacobi_tb (8 or 16 sweeps + set_bnd per launch, up to 3 fields per launch; %.1f launches/step)"
+                   % (launches / a.steps)) if a.variant == 3 else "k_jacobi_%s (one sweep + fused set_bnd)" % KERNELS[a.variant]
     line = {
         "metric": "Mcells/s per Jacobi iter", "value": mcells, "unit": "Mcells/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
@@ -240,14 +236,16 @@ def main():
         "roofline": {"bound": "hbm", "kernel": kernel_name,
                      "achieved": achieved * (1.0 / world), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / world / HBM_PEAK_GBS, "traffic": None,
-                     "sweeps_per_launch": fused,
-                     "note": ("per GPU: algorithmic 12 B/cell/sweep x %d cells x %d sweeps per launch / mean launch "
-                              "time, HIP events over %d timed sweeps" % (cells // world, fused, sweeps)) + (
+                     "launches": launches, "mean_launch_us": jac_ms * 1e3 / launches,
+                     "algorithmic_bytes_per_launch": bpc * (cells // world) * per_launch,
+                     "note": ("per GPU: algorithmic 12 B/cell/sweep x %d cells x %.1f field-sweeps per launch / mean "
+                              "launch time, HIP events on the solver's stream over %d timed launches"
+                              % (cells // world, per_launch, launches)) + (
                                  "; temporal blocking keeps the intermediate sweeps on chip, so the algorithmic "
-                                 "rate may exceed the HBM peak -- frac_compulsory prices one launch at its own "
-                                 "compulsory traffic (read x, x0, write x once = 12 B/cell)" if fused > 1 else "")},
+                                 "rate may exceed the HBM peak -- frac_compulsory prices each launch at its own "
+                                 "compulsory traffic (read x, x0, write x once per field = 12 B/cell)" if a.variant == 3 else "")},
     }
-    line["roofline"]["frac_compulsory"] = line["roofline"]["frac"] / fused
+    line["roofline"]["frac_compulsory"] = bpc * (cells / world) * field_launches / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     tr = pmc_traffic("k_jacobi_%s" % KERNELS[a.variant], grid) if world == 1 else None
     if tr:
         line["roofline"]["traffic"] = tr[0]
@@ -255,7 +253,7 @@ def main():
     if calls:
         line["exchanges_per_rank"] = {"halo": calls[0], "gather": calls[1], "max": calls[2]}
     if world == 1 and not a.no_scaling_base and grid != 8192:
-        (e2, j2, s2), _, _ = run(8190, max(a.steps // 4, 3), 2)
+        (e2, j2, s2, _l2, _f2), _, _ = run(8190, max(a.steps // 4, 3), 2)
         ts2 = j2 * 1e-3 / max(s2, 1)
         line["scaling_base"] = {"workload": "8192x8192 on 1 GPU", "value": 8192 * 8192 / ts2 / 1e6, "unit": "Mcells/s",
                                 "ms_per_step": e2 * 1e3 / max(a.steps // 4, 3),

@@ -90,7 +90,7 @@ struct fluid_ctx {
     size_t ev_used = 0;
     double cat_ms[FLUID_TIMING_CATEGORIES] = {};
     long long cat_calls[FLUID_TIMING_CATEGORIES] = {};
-    long long sweeps = 0, pending_sweeps = 0;
+    long long sweeps = 0, pending_sweeps = 0, launches = 0, field_launches = 0;
 
     bool valid_field(int id) const { return id >= 0 && id < FLUID_NFIELDS; }
     void* row(int id, int r) const { return static_cast<char*>(f[id]) + (size_t)r * pitch * esz; }
@@ -454,6 +454,10 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
             for (int j = 0; j < count; ++j)
                 fluid::launch_jacobi(c->stream, c->st, v, c->f[cur[j]], c->f[sv[j].x0], c->f[nxt[j]], c->pitch, c->n, lo, hi,
                                      sv[j].alpha, sv[j].beta, sv[j].b);
+            if (c->timing) {
+                c->launches += count;
+                c->field_launches += count;
+            }
         } else {
             // one launch per group of solves that share a division mode (normally: all of them)
             for (int first = 0; first < count;) {
@@ -501,6 +505,10 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 // edge windows (ghost columns) cost ~1.6x per row: shorter strips there keep the launch balanced
                 const int rb_edge = std::min(rb, edge_rows(rb));
                 fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], c->tb_nv, bt, c->pitch, c->n, lo, hi, rb, rb_edge);
+                if (c->timing) {
+                    c->launches += 1;
+                    c->field_launches += m;
+                }
                 first = last;
             }
         }
@@ -1214,6 +1222,8 @@ int fluid_timing_read(fluid_ctx* c, fluid_timing* out, int reset)
     TRY(timing_collect(c));
     out->jacobi_ms = c->cat_ms[FLUID_TIME_DIFFUSION];
     out->sweeps = c->sweeps;
+    out->jacobi_launches = c->launches;
+    out->jacobi_field_launches = c->field_launches;
     out->solves = c->cat_calls[FLUID_TIME_DIFFUSION];
     for (int k = 0; k < FLUID_TIMING_CATEGORIES; ++k) {
         out->category_ms[k] = c->cat_ms[k];
@@ -1225,6 +1235,7 @@ int fluid_timing_read(fluid_ctx* c, fluid_timing* out, int reset)
             c->cat_calls[k] = 0;
         }
         c->sweeps = 0;
+        c->launches = c->field_launches = 0;
     }
     return FLUID_OK;
 }

@@ -180,6 +180,9 @@ typedef struct fluid_timing {
     long long solves;
     double category_ms[FLUID_TIMING_CATEGORIES];
     long long category_calls[FLUID_TIMING_CATEGORIES];
+    long long jacobi_launches;        /* Jacobi kernel launches in those solves                              */
+    long long jacobi_field_launches;  /* the same, counting a launch once per field it sweeps (a batched launch
+                                         sweeps up to three): x12 B x cells = the launches' compulsory bytes */
 } fluid_timing;
 int fluid_timing_enable(fluid_ctx *ctx, int on);
 int fluid_timing_read(fluid_ctx *ctx, fluid_timing *out, int reset);
