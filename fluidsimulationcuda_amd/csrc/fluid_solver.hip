@@ -68,7 +68,7 @@ struct fluid_ctx {
     hipEvent_t scalar_ready = nullptr;    // recorded behind the scalar's device-to-host copy
     int variant = fluid::JACOBI_TB;
     int tb_max_t = 16, tb_rows = 0, num_cu = 256;   // temporal blocking: sweeps/launch cap, rows/strip (0 = auto)
-    long long tb_min_cells = 1500000;              // smaller slabs use single-sweep launches
+    long long tb_min_cells = 0;                    // smaller slabs use single-sweep launches (never faster since the 2-column lanes)
     bool defer_zero_source = true;                 // see settle()
     bool in_halo_exchange = false;
     int tb_nv = 2;                                 // columns per lane of the fused kernel (2: 4 waves/SIMD; 4: 2 waves/SIMD)
@@ -408,9 +408,9 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         return r;
     };
     int r = multi ? reach_now() : kEverywhere;            // sweeps possible right now
-    // below ~1.5M cells per slab a sweep is bound by launch latency, not bytes: the 256-column
-    // windows of the blocked kernel cannot fill 256 CUs and one thread per cell is fastest
-    // (measured crossover ~1300^2, profiles/r01_config1_1024.md)
+    // FLUID_PARAM_TB_MIN_CELLS: slabs below it run one launch per sweep.  Default 0: with 2-column
+    // lanes the fused kernel wins at every size measured (32^2 .. 16384^2) -- tiny grids are bound by
+    // launch latency and it needs 5 launches per solve instead of 40.
     // fp16 storage rounds once per launch, so there the launch schedule is part of the result: it
     // must not depend on how the grid is split, how deep the ghost zones are or how solves are
     // batched.  It is derived from the global problem alone and a short reach triggers an early
@@ -428,8 +428,10 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
             // launch schedule, which stays the 8-sweep one)
             // -- where they pay: the pressure form (a packed multiply per pair) is bound by memory at every
             // size; the general form (a double-precision multiply per cell) is bound by arithmetic, which
-            // deeper blocking only adds to, until the fields outgrow the 256 MB Infinity Cache
-            if (room >= 16 && c->tb_max_t >= 16 && c->tb_nv == 2 && !canonical && (all_mode4 || c->field_bytes > (96ull << 20)))
+            // deeper blocking only adds to, until the fields outgrow the 256 MB Infinity Cache.  Grids under
+            // 8 M cells do not have the rows to fill the chip with 16-sweep strips (measured: 8 wins up to 3072^2).
+            if (room >= 16 && c->tb_max_t >= 16 && c->tb_nv == 2 && !canonical && (long long)c->n * c->n >= (8ll << 20) &&
+                (all_mode4 || c->field_bytes > (96ull << 20)))
                 return 16;
             return (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
         };

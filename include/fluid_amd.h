@@ -62,7 +62,7 @@ enum {
     ,FLUID_PARAM_TB_LANE_COLUMNS = 6 /* columns per lane of FLUID_JACOBI_TB: 2 (default; thin waves, 4 per SIMD)
                                       or 4 (2 per SIMD): speed only                                      */
     ,FLUID_PARAM_TB_MIN_CELLS = 4  /* FLUID_JACOBI_TB fuses sweeps only on slabs of at least this many cells
-                                      (default 1 500 000); smaller ones run one-thread-per-cell sweeps   */
+                                      (default 0: always); smaller ones run one-thread-per-cell sweeps   */
 };
 
 typedef struct fluid_ctx fluid_ctx;

@@ -227,18 +227,18 @@ def test_step_tb_equals_step_stream_at_4096(F):
         assert_bit_equal(b, a, "full steps, TB vs stream: " + k)
 
 
-def test_small_grids_fall_back_to_single_sweeps_with_same_bits(F):
-    """Below PARAM_TB_MIN_CELLS the default kernel choice runs one-thread-per-cell
-    sweeps; forcing the fused kernel on the same problem gives the same bits."""
+def test_small_grids_fused_and_single_sweep_launches_give_the_same_bits(F):
+    """PARAM_TB_MIN_CELLS (default 0: always fuse) sends slabs below it to one-thread-per-cell
+    sweeps; both choices give the same bits."""
     from fluidsimulationcuda_amd.harness import initialize_parameters
     n = 510
     f = initialize_parameters(n)
     res = []
-    for params in (None, {4: 0}):
+    for params in (None, {4: 1 << 30}):
         with F.FluidSolver(n, params=params) as s:
             s.upload(**f)
             s.step(1, use_sources=True)
             s.step(1)
             res.append([s.download(k) for k in ("u", "v", "dens")])
     for a, b, k in zip(res[0], res[1], "uvd"):
-        assert_bit_equal(b, a, "auto vs forced fusion: " + k)
+        assert_bit_equal(b, a, "fused (default) vs single-sweep launches: " + k)
