@@ -4,6 +4,10 @@ and ms per simulation step of the Stable-Fluids vel_step + dens_step.
 
   python bench.py [--gpus N --steps K --warmup W]      (N>1: under torch.distributed.run)
 
+`value` follows SURVEY.md 8(d): W^2 / t_sweep with t_sweep the mean time of one sweep (set_bnd included) of the
+40-sweep pressure solves (alpha 1, beta 4, b 0) inside the timed steps, HIP events on the solver's stream;
+`all_solves` is the same rate over all 200 sweeps of a step, and the `roofline` object prices ALL Jacobi launches.
+
 A "step" is one loop body of the reference's main (FluidSequential.c:298-306):
 sources zeroed, vel_step, dens_step, 40 Jacobi sweeps per solve = 200 sweeps,
 3 advects, 2 projections.  Fields are resident in HBM when the timed region
@@ -57,7 +61,7 @@ def parse():
 def measure(solver, dist, world, steps, warmup, iters, cells):
     """W untimed steps, then exactly K timed steps between barrier+synchronize
     pairs; returns (max-over-ranks seconds, max-over-ranks Jacobi ms, sweeps, Jacobi launches,
-    launches counted once per field swept)."""
+    launches counted once per field swept, max-over-ranks ms in the pressure solves, their sweeps)."""
     import torch
     solver.step(1, use_sources=True, iters=iters)          # z == 0 consumes the synthetic sources
     for _ in range(max(warmup - 1, 0)):
@@ -75,13 +79,13 @@ def measure(solver, dist, world, steps, warmup, iters, cells):
     elapsed = time.perf_counter() - t0
     t = solver.timing_read(reset=True)
     solver.timing_enable(False)
-    jac_ms, sweeps = t["jacobi_ms"], t["sweeps"]
+    jac_ms, sweeps, prs_ms = t["jacobi_ms"], t["sweeps"], t["pressure_ms"]
     if world > 1:
-        buf = torch.tensor([elapsed, jac_ms], dtype=torch.float64,
+        buf = torch.tensor([elapsed, jac_ms, prs_ms], dtype=torch.float64,
                            device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(buf, op=dist.ReduceOp.MAX)
-        elapsed, jac_ms = float(buf[0]), float(buf[1])
-    return elapsed, jac_ms, sweeps, t["jacobi_launches"], t["jacobi_field_launches"]
+        elapsed, jac_ms, prs_ms = float(buf[0]), float(buf[1]), float(buf[2])
+    return elapsed, jac_ms, sweeps, t["jacobi_launches"], t["jacobi_field_launches"], prs_ms, t["pressure_sweeps"]
 
 
 def pmc_traffic(kernel, grid):
@@ -209,10 +213,11 @@ def main():
                     sys.exit("rank %d: %s differs between %d slabs and one context" % (rank, k, world))
         if rank == 0:
             print("check ok: %d slabs bit-identical to one context at %dx%d" % (world, grid, grid), file=sys.stderr)
-    (elapsed, jac_ms, sweeps, launches, field_launches), fields, calls = run(n, a.steps, a.warmup)
+    (elapsed, jac_ms, sweeps, launches, field_launches, prs_ms, prs_sweeps), fields, calls = run(n, a.steps, a.warmup)
     ms_step = elapsed * 1e3 / a.steps
-    t_sweep = jac_ms * 1e-3 / max(sweeps, 1)
-    mcells = cells / t_sweep / 1e6
+    t_sweep = jac_ms * 1e-3 / max(sweeps, 1)             # all 200 sweeps of the step
+    t_psweep = prs_ms * 1e-3 / max(prs_sweeps, 1)        # the pressure solves: SURVEY.md 8(d)'s definition of the metric
+    mcells = cells / t_psweep / 1e6
     bpc = BYTES_PER_CELL_SWEEP // (2 if a.dtype == "f16" else 1)
     achieved = bpc * cells / t_sweep / 1e9
     launches = max(launches, 1)
@@ -231,7 +236,10 @@ def main():
                    "parallelism": "1 GPU" if world == 1 else "row slabs x%d, %s halo rows" % (
                        world, "RCCL" if a.backend == "nccl" else a.backend + " (host-staged rehearsal)")},
         "ms_per_sim_step": ms_step,
-        "us_per_jacobi_sweep": t_sweep * 1e6,
+        "us_per_jacobi_sweep": t_psweep * 1e6,
+        "all_solves": {"value": cells / t_sweep / 1e6, "unit": "Mcells/s", "us_per_jacobi_sweep": t_sweep * 1e6,
+                       "note": "the same rate over all 200 sweeps of the step (3 diffusions, whose exact division "
+                               "by 1+4a costs more than the pressure solve's multiply by 1/4, + 2 pressure solves)"},
         "step_algorithmic_GBps": BYTES_PER_CELL_STEP // (2 if a.dtype == "f16" else 1) * cells / (ms_step * 1e-3) / 1e9,
         "roofline": {"bound": "hbm", "kernel": kernel_name,
                      "achieved": achieved * (1.0 / world), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -253,11 +261,12 @@ def main():
     if calls:
         line["exchanges_per_rank"] = {"halo": calls[0], "gather": calls[1], "max": calls[2]}
     if world == 1 and not a.no_scaling_base and grid != 8192:
-        (e2, j2, s2, _l2, _f2), _, _ = run(8190, max(a.steps // 4, 3), 2)
-        ts2 = j2 * 1e-3 / max(s2, 1)
+        (e2, j2, s2, _l2, _f2, p2, ps2), _, _ = run(8190, max(a.steps // 4, 3), 2)
+        ts2 = p2 * 1e-3 / max(ps2, 1)
         line["scaling_base"] = {"workload": "8192x8192 on 1 GPU", "value": 8192 * 8192 / ts2 / 1e6, "unit": "Mcells/s",
                                 "ms_per_step": e2 * 1e3 / max(a.steps // 4, 3),
-                                "roofline_frac": BYTES_PER_CELL_SWEEP * 8192 * 8192 / ts2 / 1e9 / HBM_PEAK_GBS}
+                                "all_solves_value": 8192 * 8192 / (j2 * 1e-3 / max(s2, 1)) / 1e6,
+                                "roofline_frac": BYTES_PER_CELL_SWEEP * 8192 * 8192 / (j2 * 1e-3 / max(s2, 1)) / 1e9 / HBM_PEAK_GBS}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(n, fields, a.iters)
     if rank == 0:

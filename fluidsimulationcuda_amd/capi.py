@@ -40,7 +40,8 @@ TIMING_CATEGORIES = ("source", "diffusion", "divergence", "projection", "advecti
 class Timing(C.Structure):
     _fields_ = [("jacobi_ms", C.c_double), ("sweeps", C.c_longlong), ("solves", C.c_longlong),
                 ("category_ms", C.c_double * 5), ("category_calls", C.c_longlong * 5),
-                ("jacobi_launches", C.c_longlong), ("jacobi_field_launches", C.c_longlong)]
+                ("jacobi_launches", C.c_longlong), ("jacobi_field_launches", C.c_longlong),
+                ("pressure_ms", C.c_double), ("pressure_sweeps", C.c_longlong)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int,

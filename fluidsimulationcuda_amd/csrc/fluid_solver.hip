@@ -85,12 +85,15 @@ struct fluid_ctx {
     void* xchg_user = nullptr;
     // timing
     bool timing = false;
-    struct Ev { hipEvent_t a, b; int cat; };
+    struct Ev { hipEvent_t a, b; int cat; bool pressure; };
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;
     double cat_ms[FLUID_TIMING_CATEGORIES] = {};
     long long cat_calls[FLUID_TIMING_CATEGORIES] = {};
     long long sweeps = 0, pending_sweeps = 0, launches = 0, field_launches = 0;
+    double pressure_ms = 0.0;                      // the part of cat_ms[DIFFUSION] spent in pressure solves (project())
+    long long pressure_sweeps = 0, pending_pressure_sweeps = 0;
+    bool in_pressure_solve = false;
 
     bool valid_field(int id) const { return id >= 0 && id < FLUID_NFIELDS; }
     void* row(int id, int r) const { return static_cast<char*>(f[id]) + (size_t)r * pitch * esz; }
@@ -151,6 +154,7 @@ int timing_begin(fluid_ctx* c, int cat, hipEvent_t* stop_out)
     }
     auto& p = c->ev_pool[c->ev_used++];
     p.cat = cat;
+    p.pressure = cat == FLUID_TIME_DIFFUSION && c->in_pressure_solve;
     HIP_TRY(hipEventRecord(p.a, c->stream));
     *stop_out = p.b;
     return FLUID_OK;
@@ -161,6 +165,7 @@ int timing_end(fluid_ctx* c, hipEvent_t stop, int sweeps)
     if (!stop) return FLUID_OK;
     HIP_TRY(hipEventRecord(stop, c->stream));
     c->pending_sweeps += sweeps;
+    if (c->in_pressure_solve) c->pending_pressure_sweeps += sweeps;
     return FLUID_OK;
 }
 
@@ -173,9 +178,12 @@ int timing_collect(fluid_ctx* c)
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k].a, c->ev_pool[k].b));
         c->cat_ms[c->ev_pool[k].cat] += ms;
         c->cat_calls[c->ev_pool[k].cat] += 1;
+        if (c->ev_pool[k].pressure) c->pressure_ms += ms;
     }
     c->sweeps += c->pending_sweeps;
     c->pending_sweeps = 0;
+    c->pressure_sweeps += c->pending_pressure_sweeps;
+    c->pending_pressure_sweeps = 0;
     c->ev_used = 0;
     return FLUID_OK;
 }
@@ -669,7 +677,10 @@ void coefficients(int n, float dt, float coef, float* alpha, float* beta)
 int project(fluid_ctx* c, int u, int v, int p, int div, int iters)
 {
     TRY(op_divergence(c, u, v, p, div, std::min(iters, c->halo - 1)));
-    TRY(op_diffuse(c, 0, p, div, 1.0f, 4.0f, iters, /*final_reach=*/1));
+    c->in_pressure_solve = true;            // timing only: reported separately (fluid_timing::pressure_ms)
+    const int rc_solve = op_diffuse(c, 0, p, div, 1.0f, 4.0f, iters, /*final_reach=*/1);
+    c->in_pressure_solve = false;
+    TRY(rc_solve);
     return op_subtract_gradient(c, u, v, p);
 }
 
@@ -1226,6 +1237,8 @@ int fluid_timing_read(fluid_ctx* c, fluid_timing* out, int reset)
     out->sweeps = c->sweeps;
     out->jacobi_launches = c->launches;
     out->jacobi_field_launches = c->field_launches;
+    out->pressure_ms = c->pressure_ms;
+    out->pressure_sweeps = c->pressure_sweeps;
     out->solves = c->cat_calls[FLUID_TIME_DIFFUSION];
     for (int k = 0; k < FLUID_TIMING_CATEGORIES; ++k) {
         out->category_ms[k] = c->cat_ms[k];
@@ -1238,6 +1251,8 @@ int fluid_timing_read(fluid_ctx* c, fluid_timing* out, int reset)
         }
         c->sweeps = 0;
         c->launches = c->field_launches = 0;
+        c->pressure_ms = 0.0;
+        c->pressure_sweeps = 0;
     }
     return FLUID_OK;
 }

@@ -160,7 +160,8 @@ class FluidSolver:
         t = capi.Timing()
         capi.check(capi.lib().fluid_timing_read(self._h, C.byref(t), 1 if reset else 0))
         out = {"jacobi_ms": t.jacobi_ms, "sweeps": t.sweeps, "solves": t.solves,
-               "jacobi_launches": t.jacobi_launches, "jacobi_field_launches": t.jacobi_field_launches}
+               "jacobi_launches": t.jacobi_launches, "jacobi_field_launches": t.jacobi_field_launches,
+               "pressure_ms": t.pressure_ms, "pressure_sweeps": t.pressure_sweeps}
         for k, name in enumerate(capi.TIMING_CATEGORIES):
             out[name + "_ms"] = t.category_ms[k]
             out[name + "_calls"] = t.category_calls[k]

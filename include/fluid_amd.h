@@ -183,6 +183,9 @@ typedef struct fluid_timing {
     long long jacobi_launches;        /* Jacobi kernel launches in those solves                              */
     long long jacobi_field_launches;  /* the same, counting a launch once per field it sweeps (a batched launch
                                          sweeps up to three): x12 B x cells = the launches' compulsory bytes */
+    double pressure_ms;               /* the part of jacobi_ms spent in the pressure solves of fluid_step /
+                                         fluid_vel_step (alpha 1, beta 4, b 0: FluidSequential.c:222,240)     */
+    long long pressure_sweeps;
 } fluid_timing;
 int fluid_timing_enable(fluid_ctx *ctx, int on);
 int fluid_timing_read(fluid_ctx *ctx, fluid_timing *out, int reset);
