@@ -393,17 +393,18 @@ __global__ __launch_bounds__(256) void k_jacobi_stream(const S* __restrict__ x, 
 // (iv) temporally blocked: T sweeps per launch, results identical to T launches
 // of any variant above (the only way past 12 B/cell/sweep).
 //
-// One wave = one window of 64 float4 lanes (256 columns) x one strip of `rb`
-// output rows, marching down the rows with all T sweeps in flight: at step t it
-// loads row t of x and x0 and, for s = 1..T, produces row t-s of "x after s
-// sweeps" from the three rows of stage s-1 it still holds.  Everything lives in
-// registers: per stage a three-row ring of its input, a queue of the last T x0
-// rows, and three rows of x/x0 prefetched ahead of use.  The time loop is unrolled by three so the rings rotate by renaming,
-// not by moving.  Left/right neighbours come from the adjacent lanes by DPP; a
-// wave has no one to ask at its two ends, so windows overlap by HL = ceil(T/4)
-// lanes per side and only the inner 64-2*HL lanes store (the wrong values creep
-// inwards one column per sweep and never reach them).  Strips overlap by T rows
-// per side the same way.  No LDS, no barriers.
+// One wave = one window of 64 lanes x NV columns (NV = 2: 128 columns, the
+// default; NV = 4: 256) x one strip of `rb` output rows, marching down the rows
+// with all T sweeps in flight: at step t it loads row t of x and x0 and, for
+// s = 1..T, produces row t-s of "x after s sweeps" from the three rows of stage
+// s-1 it still holds.  Everything lives in registers: per stage a three-row ring
+// of its input, a queue of the last T x0 rows, and three rows of x/x0 prefetched
+// ahead of use.  The time loop is unrolled by three so the rings rotate by
+// renaming, not by moving.  Left/right neighbours come from the adjacent lanes
+// by DPP; a wave has no one to ask at its two ends, so windows overlap by
+// HL = ceil(T/NV) lanes per side and only the inner 64-2*HL lanes store (the
+// wrong values creep inwards one column per sweep and never reach them).  Strips
+// overlap by T rows per side the same way.  No LDS, no barriers.
 //
 // set_bnd is replayed inside the pipeline (it must be: sweep s+1 reads the
 // ghosts of sweep s): the lanes holding ghost column 0 / n+1 overwrite that
@@ -415,20 +416,21 @@ __global__ __launch_bounds__(256) void k_jacobi_stream(const S* __restrict__ x, 
 // final store.  Negation is a sign-bit XOR (bit-identical to the reference's
 // unary minus, zeros and NaNs included).
 //
-// DIVMODE 0: (..)/beta, true division (about 20 VALU-op times on gfx950).
-// DIVMODE 1: beta is a power of two and `beta` carries its exact reciprocal:
-//   (..)*rbeta is the same correctly rounded result for every input (pressure
-//   solve: beta = 4).
-// DIVMODE 4: DIVMODE 1 with alpha == 1.0f, whose multiplication is the identity and is left out.
-// DIVMODE 2: (float)((double)(..) * yd) with yd = RN64(1/beta).  The double
-//   product is within 2^-52 relative of the true quotient, while a quotient of two
-//   floats is never that close to a float rounding boundary (the boundary would
-//   need an odd 25-bit significand times beta's to fit 24 bits), so the final
-//   conversion rounds exactly as IEEE division does; zeros, denormals, inf and NaN
-//   need no special case.  The one exception class -- quotients that land exactly
-//   on a denormal midpoint, possible for a few even-integer-like beta -- is why
-//   the solver proves each beta on the device before using this mode:
-//   k_validate_div compares it with a/beta for all 2^32 inputs (about 6 op times).
+// The division by the per-solve constant beta comes in three forms (DIVMODE):
+// 0: (..)/beta, true division (about 20 VALU-op times on gfx950).
+// 4: beta is a power of two and alpha == 1.0f (the pressure solve: 1, 4):
+//   `beta` carries the exact reciprocal, (..)*rbeta is the same correctly rounded
+//   result for every input, and x * 1.0f is x, so alpha is not applied at all.
+// 2: (float)((double)(..) * yd) with yd = RN64(1/beta).  The double product is
+//   within 2^-52 relative of the true quotient, while a quotient of two floats is
+//   never that close to a float rounding boundary (the boundary would need an odd
+//   25-bit significand times beta's to fit 24 bits), so the final conversion
+//   rounds exactly as IEEE division does; zeros, denormals, inf and NaN need no
+//   special case.  The one exception class -- quotients that land exactly on a
+//   denormal midpoint, possible for a few even-integer-like beta -- is why the
+//   solver proves each beta on the device before using modes 2 and 4:
+//   k_validate_div compares them with a/beta for all 2^32 inputs.
+
 // One lane's share of a row: NV consecutive columns (NV = 2 or 4).
 template <int NV>
 struct Vec {
