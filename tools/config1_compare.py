@@ -56,7 +56,7 @@ def report():
                         pmc[r["Counter_Name"]].append(float(r["Counter_Value"]) * 1024)
         fetch = 2 * sum(pmc["FETCH_SIZE"]) / max(len(pmc["FETCH_SIZE"]), 1)
         write = sum(pmc["WRITE_SIZE"]) / max(len(pmc["WRITE_SIZE"]), 1)
-        sweeps = b["roofline"].get("sweeps_per_launch", 1)
+        sweeps = b["roofline"]["algorithmic_bytes_per_launch"] / (12.0 * cells)      # field-sweeps per launch (mean)
         rows.append((name, kern["Name"].split("(")[0].replace("void fluid::", ""), float(kern["AverageNs"]) / 1e3, sweeps,
                      b["us_per_jacobi_sweep"], b["value"], 12 * cells / (b["us_per_jacobi_sweep"] * 1e-6) / 1e9,
                      (fetch + write) / 1e6, b["ms_per_step"]))
@@ -65,10 +65,10 @@ def report():
              "then `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes; reads x2-corrected for gfx950).",
              "Algorithmic traffic of one sweep at 1024^2 = 12 B x 1 048 576 cells = 12.6 MB: the whole working set",
              "(3 fields x 4.2 MB) sits in L2/Infinity Cache, so this size measures launch + on-chip behaviour, not HBM.", "",
-             "| variant | kernel (dominant instantiation) | avg launch (us) | sweeps/launch | us / sweep (HIP events) | Mcells/s per iter | algorithmic GB/s | PMC HBM MB / launch | ms / sim step |",
+             "| variant | kernel (dominant instantiation) | avg launch (us) | field-sweeps/launch (mean) | us / sweep (HIP events) | Mcells/s per iter | algorithmic GB/s | PMC HBM MB / launch | ms / sim step |",
              "|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
-        lines.append("| %s | `%s` | %.2f | %d | %.2f | %.0f | %.0f | %.1f | %.3f |" % r)
+        lines.append("| %s | `%s` | %.2f | %.1f | %.2f | %.0f | %.0f | %.1f | %.3f |" % r)
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     path = os.path.join(ROOT, "profiles", "r01_config1_1024.md")
     open(path, "w").write("\n".join(lines) + "\n")
