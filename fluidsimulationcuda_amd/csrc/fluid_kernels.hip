@@ -58,7 +58,7 @@ __device__ __forceinline__ void st4(half_t* p, const float4& v)
     *reinterpret_cast<half4_t*>(p) = h;
 }
 
-// Buffer-resource forms of ld4/st4 for the fused kernel's steady state: the
+// Range-checked buffer loads/stores (buf_ldv / buf_stv below) for the fused kernel's steady state: the
 // hardware range check (offset >= num_records: loads return 0, stores are
 // dropped) replaces every `if` around a memory operation, so the loop body has a
 // fixed number of them and hipcc can emit counted s_waitcnt vmcnt(N) instead of
@@ -68,44 +68,6 @@ __device__ __forceinline__ void st4(half_t* p, const float4& v)
 constexpr unsigned kBufOff = 0x80000000u;
 typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
 typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float4 buf_ld4(const float*, __amdgpu_buffer_rsrc_t r, unsigned off)
-{
-    const uint4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-}
-__device__ __forceinline__ float4 buf_ld4(const half_t*, __amdgpu_buffer_rsrc_t r, unsigned off)
-{
-    const uint2_t u = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
-    half4_t h;
-    __builtin_memcpy(&h, &u, 8);
-    return make_float4(keep_f32((float)h.x), keep_f32((float)h.y), keep_f32((float)h.z), keep_f32((float)h.w));
-}
-__device__ __forceinline__ void buf_st4(float*, __amdgpu_buffer_rsrc_t r, unsigned off, const float4& v)
-{
-    uint4_t u;
-    u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, off, 0, 0);
-}
-__device__ __forceinline__ void buf_st4(half_t*, __amdgpu_buffer_rsrc_t r, unsigned off, const float4& v)
-{
-    half4_t h;
-    h.x = (half_t)keep_f32(v.x); h.y = (half_t)keep_f32(v.y); h.z = (half_t)keep_f32(v.z); h.w = (half_t)keep_f32(v.w);
-    uint2_t u;
-    __builtin_memcpy(&u, &h, 8);
-    __builtin_amdgcn_raw_buffer_store_b64(u, r, off, 0, 0);
-}
-
-__device__ __forceinline__ void buf_st1(float*, __amdgpu_buffer_rsrc_t r, unsigned off, float v)
-{
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0);
-}
-__device__ __forceinline__ void buf_st1(half_t*, __amdgpu_buffer_rsrc_t r, unsigned off, float v)
-{
-    const half_t h = (half_t)keep_f32(v);
-    unsigned short u;
-    __builtin_memcpy(&u, &h, 2);
-    __builtin_amdgcn_raw_buffer_store_b16(u, r, off, 0, 0);
-}
 
 // value of lane-1 / lane+1 across the whole 64-wide wave (DPP wave shifts; one
 // VALU op each, no LDS).  Lane 0 / 63 receive `edge`.
@@ -630,7 +592,7 @@ __device__ __forceinline__ void tb_fix_columns(Vec<NV>& G, const TbArgs<S, NV>& 
 // buffer: the ragged last vector and the two ghost-column lanes spill their surplus components
 // into pad floats (never read as data), so edge windows issue the same single store per step as
 // interior ones; wall strips add the two ghost rows, enabled by a select on the offset.  A fixed
-// number of memory operations per step is what lets hipcc count them (see buf_ld4).
+// number of memory operations per step is what lets hipcc count them (see kBufOff).
 template <bool EDGE, bool WALL, typename S, int NV>
 __device__ __forceinline__ void tb_store(const Vec<NV>& G, int q, bool mine, const TbArgs<S, NV>& a, float v1, float vn)
 {

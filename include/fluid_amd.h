@@ -45,7 +45,7 @@ enum {
 };
 
 /* Jacobi kernels (identical results, different data paths).  TB = temporally
- * blocked: up to 8 sweeps per launch, same bits as 8 single-sweep launches. */
+ * blocked: up to 16 sweeps per launch, same bits as that many single-sweep launches. */
 enum { FLUID_JACOBI_STREAM = 0, FLUID_JACOBI_LDS = 1, FLUID_JACOBI_NAIVE = 2, FLUID_JACOBI_TB = 3 };
 
 /* Tuning knobs for fluid_set_param(); none of them changes results. */
