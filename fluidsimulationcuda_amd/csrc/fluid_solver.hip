@@ -426,6 +426,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
     const bool canonical = c->st == fluid::STORAGE_F16;
     const bool small = (canonical ? (long long)c->n * c->n : (long long)(c->own1 - c->own0) * c->n * count) <
                        c->tb_min_cells;
+    const long long slab_cells = (long long)(c->own1 - c->own0) * c->n;       // what this rank sweeps (the whole grid on one GPU)
     for (int k = 0; k < iters;) {
         const int remaining = iters - k;
         auto pick = [&](int room) {
@@ -436,10 +437,10 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
             // launch schedule, which stays the 8-sweep one)
             // -- where they pay: the pressure form (a packed multiply per pair) is bound by memory at every
             // size; the general form (a double-precision multiply per cell) is bound by arithmetic, which
-            // deeper blocking only adds to, until the fields outgrow the 256 MB Infinity Cache.  Grids under
-            // 8 M cells do not have the rows to fill the chip with 16-sweep strips (measured: 8 wins up to 3072^2).
-            if (room >= 16 && c->tb_max_t >= 16 && c->tb_nv == 2 && !canonical && (long long)c->n * c->n >= (8ll << 20) &&
-                (all_mode4 || c->field_bytes > (96ull << 20)))
+            // deeper blocking only adds to, until the fields outgrow the 256 MB Infinity Cache.  Grids (or slabs)
+            // under 8 M cells do not have the rows to fill the chip with 16-sweep strips (measured: 8 wins up to 3072^2).
+            if (room >= 16 && c->tb_max_t >= 16 && c->tb_nv == 2 && !canonical && slab_cells >= (8ll << 20) &&
+                (all_mode4 || (unsigned long long)slab_cells * c->esz > (96ull << 20)))
                 return 16;
             return (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
         };

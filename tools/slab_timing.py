@@ -54,7 +54,17 @@ with F.FluidSolver(n, rank=P // 2 - 1 if P > 1 else 0, nranks=P) as s:
         wall = (time.perf_counter() - t0) / K
         t = s.timing_read(reset=True)
         s.timing_enable(False)
-        print("grid %d, rank of %d (rows %d..%d), strip rows %3d: %.3f ms/step, %.2f us per Jacobi sweep, "
-              "%d halo + %d max exchanges per step" % (grid, P, lo, hi, rows, wall * 1e3,
-                                                        t["jacobi_ms"] * 1e3 / t["sweeps"], calls["halo"] // K, calls["max"] // K),
-              flush=True)
+        gpu = sum(t[k + "_ms"] for k in capi.TIMING_CATEGORIES) / K
+        print("grid %d, rank of %d (rows %d..%d), strip rows %3d: %.3f ms/step wall (timing on), %.3f ms/step in kernels "
+              "(%s), %.2f us per Jacobi sweep, %d halo + %d max exchanges per step"
+              % (grid, P, lo, hi, rows, wall * 1e3, gpu, ", ".join("%s %.3f" % (k, t[k + "_ms"] / K) for k in capi.TIMING_CATEGORIES),
+                 t["jacobi_ms"] * 1e3 / t["sweeps"], calls["halo"] // K, calls["max"] // K), flush=True)
+        # the same without the timing events (they add host work and stream markers)
+        s.step(2)
+        s.synchronize()
+        t0 = time.perf_counter()
+        s.step(K)
+        t_enq = time.perf_counter() - t0
+        s.synchronize()
+        print("   timing off: %.3f ms/step wall, host enqueue alone %.3f ms/step" % ((time.perf_counter() - t0) / K * 1e3,
+                                                                                    t_enq / K * 1e3), flush=True)
