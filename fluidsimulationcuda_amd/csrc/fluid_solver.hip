@@ -424,8 +424,9 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
     // batched.  It is derived from the global problem alone and a short reach triggers an early
     // exchange instead of a shorter launch.  (fp32 results do not depend on the schedule.)
     const bool canonical = c->st == fluid::STORAGE_F16;
-    // what a rank sweeps (the whole grid on one GPU).  From the base slab height, NOT this rank's own (ranks differ by a
-    // row when N does not divide evenly): every rank must pick the same launch depths, or their exchanges stop pairing up
+    // what a rank sweeps (the whole grid on one GPU).  From the base slab height, not this rank's own (ranks differ by a
+    // row when N does not divide evenly), so that every rank takes the same size-dependent decisions.  (Exchanges are
+    // driven by `reach`, which every sweep consumes alike whatever the launch depth, so they would pair up regardless.)
     const long long slab_cells = (long long)(c->nranks > 1 ? c->min_slab : c->n) * c->n;
     const bool small = (canonical ? (long long)c->n * c->n : slab_cells * count) < c->tb_min_cells;
     for (int k = 0; k < iters;) {

@@ -66,14 +66,14 @@ class FakeFabric:
         return cb
 
 
-def run_ranks(n, nranks, halo, fields, body, jacobi=0, storage=0):
+def run_ranks(n, nranks, halo, fields, body, jacobi=0, storage=0, params=None):
     """Run body(solver) on every fake rank; returns the gathered fields."""
     from fluidsimulationcuda_amd.slab import SlabSolver
     fab = FakeFabric(nranks)
     solvers = []
     for r in range(nranks):
         s = SlabSolver.__new__(SlabSolver)
-        _init_fake(s, n, r, nranks, halo, jacobi, storage)
+        _init_fake(s, n, r, nranks, halo, jacobi, storage, params)
         s.set_exchange(fab.make_callback(r))
         fab.solvers[r] = s
         s.load_global(**fields)
@@ -106,7 +106,7 @@ def run_ranks(n, nranks, halo, fields, body, jacobi=0, storage=0):
     return out, fab
 
 
-def _init_fake(s, n, rank, nranks, halo, jacobi, storage=0):
+def _init_fake(s, n, rank, nranks, halo, jacobi, storage=0, params=None):
     """SlabSolver.__init__ minus the torch.distributed exchange."""
     import ctypes as C
     import torch
@@ -123,7 +123,7 @@ def _init_fake(s, n, rank, nranks, halo, jacobi, storage=0):
     FluidSolver.__init__(s, n, rank=rank, nranks=nranks, halo=halo, jacobi=jacobi,
                          stream=s.torch_stream.cuda_stream,
                          arena_ptr=s.arena.data_ptr(), arena_bytes=nbytes, storage=storage,
-                         params={capi.PARAM_TB_MIN_CELLS: 0})     # fuse sweeps even on these small slabs
+                         params={capi.PARAM_TB_MIN_CELLS: 0, **(params or {})})   # fuse sweeps even on small slabs
     esz, dt = (2, torch.float16) if storage else (4, torch.float32)
     s._fb = ff.value * esz
     s._views = [s.arena[k * s._fb:(k + 1) * s._fb].view(dt).view(n + 2, s.pitch) for k in range(capi.NFIELDS)]
@@ -161,6 +161,8 @@ def test_steps_bit_identical_to_one_gpu(n, nranks, halo, jacobi):
     for k in ("u", "v", "dens"):
         assert_bit_equal(got[k], want[k], "%s, %d slabs halo %d kernel %d" % (k, nranks, halo, jacobi))
     from fluidsimulationcuda_amd import capi
+    for r in range(1, nranks):                            # collectives pair up only if every rank asks for the same ones
+        assert fab.log[r] == fab.log[0], "rank %d issued a different exchange sequence" % r
     kinds = [e[0] for e in fab.log[0]]
     assert kinds.count(capi.XCHG_MAX_END) == 2 * 3        # two advect bounds per step
     # deep ghost zones: far fewer halo exchanges than the 200 sweeps of a step
@@ -171,6 +173,27 @@ def test_steps_bit_identical_to_one_gpu(n, nranks, halo, jacobi):
         # tall slabs, deep ghost zones: diffusion x3 share one exchange, each projection
         # needs one, each advect at most one (SURVEY.md 8(e) asks for one PER SWEEP: 200)
         assert kinds.count(capi.XCHG_HALO) <= 3 * 5
+
+
+@pytest.mark.parametrize("min_cells", [31 * 126 + 1, 32 * 126, 32 * 126 * 3 - 5])
+def test_uneven_slabs_take_the_same_decisions(min_cells):
+    """126 rows over 4 ranks = slabs of 32, 32, 31, 31 rows.  Size-dependent choices (fuse sweeps or not,
+    how many per launch) with their thresholds placed between the two slab sizes: every rank must
+    still issue the same exchange sequence, and the result must not change."""
+    from fluidsimulationcuda_amd import capi
+    n, nranks = 126, 4
+    fields = synthetic(n, seed=5)
+
+    def body(s):
+        s.step(1, use_sources=True)
+        s.step(1)
+
+    want = single(n, fields, body)
+    got, fab = run_ranks(n, nranks, 6, fields, body, jacobi=3, params={capi.PARAM_TB_MIN_CELLS: min_cells})
+    for r in range(1, nranks):
+        assert fab.log[r] == fab.log[0], "rank %d issued a different exchange sequence" % r
+    for k in ("u", "v", "dens"):
+        assert_bit_equal(got[k], want[k], "%s with TB_MIN_CELLS=%d" % (k, min_cells))
 
 
 def test_advect_large_velocity_falls_back_to_gather():
