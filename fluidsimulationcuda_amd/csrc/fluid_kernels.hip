@@ -872,77 +872,105 @@ __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbB
 }
 
 // ---------------------------------------------------------------------------
-// a5  advect (FluidSequential.c:107-141): one thread per cell; the wave reads
-// 64 consecutive u,v (coalesced) and gathers the four bilinear taps of d0.
+// a5  advect (FluidSequential.c:107-141): the velocity streams in coalesced, the
+// four bilinear taps of d0 per cell are gathered (served by L2 / Infinity Cache).
 // ---------------------------------------------------------------------------
+// Each thread takes four consecutive cells of a row: the velocity comes in and the result goes out as
+// one 16-byte access per field (4-byte accesses left these kernels at half the bandwidth of the other
+// streaming kernels), and the four back-traces give the memory system 16 or 32 independent taps per
+// thread to work on.  Per cell the arithmetic is the reference's, in its order.
+struct AdvectTap {
+    size_t o;             // offset of the top-left tap
+    float s0, s1, t0, t1;
+};
+
+__device__ __forceinline__ AdvectTap advect_trace(int j, int i, float uu, float vv, float dt0, int n, size_t P)
+{
+    float px = (float)j - dt0 * uu;
+    float py = (float)i - dt0 * vv;
+    const float hi = (float)n + 0.5f;
+    if (px < 0.5f) px = 0.5f;
+    if (px > hi) px = hi;
+    if (py < 0.5f) py = 0.5f;
+    if (py > hi) py = hi;
+    const int j0 = (int)px, i0 = (int)py;
+    AdvectTap t;
+    t.s1 = px - (float)j0;
+    t.s0 = 1.0f - t.s1;
+    t.t1 = py - (float)i0;
+    t.t0 = 1.0f - t.t1;
+    t.o = (size_t)i0 * P + XOFF + j0;
+    return t;
+}
+
+template <typename S>
+__device__ __forceinline__ float advect_sample(const S* __restrict__ d0, size_t P, const AdvectTap& t)
+{
+    const S* q = d0 + t.o;
+    const float a = t.t0 * ld1(q) + t.t1 * ld1(q + P);
+    const float e = t.t0 * ld1(q + 1) + t.t1 * ld1(q + P + 1);
+    return t.s0 * a + t.s1 * e;
+}
+
+// store four results starting at column j (16-byte aligned), the ragged end of a row cell by cell
+template <typename S>
+__device__ __forceinline__ void advect_store(S* __restrict__ d, size_t P, int n, int b, int j, int i, const float (&val)[4])
+{
+    S* row = d + (size_t)i * P + XOFF + j;
+    if (j + 3 <= n) {
+        st4(row, make_float4(val[0], val[1], val[2], val[3]));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (j + k <= n) st1(row + k, val[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (j + k <= n) emit_ghosts(d, P, n, b, j + k, i, val[k]);
+}
+
 template <typename S>
 __global__ __launch_bounds__(256) void k_advect(S* __restrict__ d, const S* __restrict__ d0, const S* __restrict__ u,
                                                 const S* __restrict__ v, int pitch, int n, int row_lo, int row_hi,
                                                 float dt0, int b)
 {
-    const int j = 1 + blockIdx.x * 256 + threadIdx.x;
+    const int j = 1 + 4 * (blockIdx.x * 256 + threadIdx.x);
     const int i = row_lo + blockIdx.y;
     if (j > n || i >= row_hi) return;
     const size_t P = (size_t)pitch;
     const size_t c = (size_t)i * P + XOFF + j;
-    float px = (float)j - dt0 * ld1(u + c);
-    float py = (float)i - dt0 * ld1(v + c);
-    const float hi = (float)n + 0.5f;
-    if (px < 0.5f) px = 0.5f;
-    if (px > hi) px = hi;
-    if (py < 0.5f) py = 0.5f;
-    if (py > hi) py = hi;
-    const int j0 = (int)px, i0 = (int)py;
-    const float s1 = px - (float)j0, s0 = 1.0f - s1;
-    const float t1 = py - (float)i0, t0 = 1.0f - t1;
-    const S* q = d0 + (size_t)i0 * P + XOFF + j0;
-    const float a = t0 * ld1(q) + t1 * ld1(q + P);
-    const float e = t0 * ld1(q + 1) + t1 * ld1(q + P + 1);
-    const float val = s0 * a + s1 * e;
-    st1(d + c, val);
-    emit_ghosts(d, P, n, b, j, i, val);
+    const float4 u4 = ld4(u + c), v4 = ld4(v + c);       // columns past n read pad / ghost floats: unused
+    const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    float val[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) val[k] = advect_sample(d0, P, advect_trace(j + k, i, uu[k], vv[k], dt0, n, P));
+    advect_store(d, P, n, b, j, i, val);
 }
 
 // Two advections along the same velocity field in one pass (vel_step advects u and v, both along
 // (u0, v0), FluidSequential.c:213-214): the velocity is read and the back-trace computed once, and
-// the eight taps of the two sources sit at the same offsets.  Per field the arithmetic is k_advect's.
+// the eight taps of the two sources sit at the same offsets.
 template <typename S>
 __global__ __launch_bounds__(256) void k_advect2(S* __restrict__ da, const S* __restrict__ d0a, int ba, S* __restrict__ db,
                                                  const S* __restrict__ d0b, int bb, const S* __restrict__ u,
                                                  const S* __restrict__ v, int pitch, int n, int row_lo, int row_hi, float dt0)
 {
-    const int j = 1 + blockIdx.x * 256 + threadIdx.x;
+    const int j = 1 + 4 * (blockIdx.x * 256 + threadIdx.x);
     const int i = row_lo + blockIdx.y;
     if (j > n || i >= row_hi) return;
     const size_t P = (size_t)pitch;
     const size_t c = (size_t)i * P + XOFF + j;
-    float px = (float)j - dt0 * ld1(u + c);
-    float py = (float)i - dt0 * ld1(v + c);
-    const float hi = (float)n + 0.5f;
-    if (px < 0.5f) px = 0.5f;
-    if (px > hi) px = hi;
-    if (py < 0.5f) py = 0.5f;
-    if (py > hi) py = hi;
-    const int j0 = (int)px, i0 = (int)py;
-    const float s1 = px - (float)j0, s0 = 1.0f - s1;
-    const float t1 = py - (float)i0, t0 = 1.0f - t1;
-    const size_t o = (size_t)i0 * P + XOFF + j0;
-    {
-        const S* q = d0a + o;
-        const float a = t0 * ld1(q) + t1 * ld1(q + P);
-        const float e = t0 * ld1(q + 1) + t1 * ld1(q + P + 1);
-        const float val = s0 * a + s1 * e;
-        st1(da + c, val);
-        emit_ghosts(da, P, n, ba, j, i, val);
+    const float4 u4 = ld4(u + c), v4 = ld4(v + c);
+    const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    float va[4], vb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const AdvectTap t = advect_trace(j + k, i, uu[k], vv[k], dt0, n, P);
+        va[k] = advect_sample(d0a, P, t);
+        vb[k] = advect_sample(d0b, P, t);
     }
-    {
-        const S* q = d0b + o;
-        const float a = t0 * ld1(q) + t1 * ld1(q + P);
-        const float e = t0 * ld1(q + 1) + t1 * ld1(q + P + 1);
-        const float val = s0 * a + s1 * e;
-        st1(db + c, val);
-        emit_ghosts(db, P, n, bb, j, i, val);
-    }
+    advect_store(da, P, n, ba, j, i, va);
+    advect_store(db, P, n, bb, j, i, vb);
 }
 
 // ---------------------------------------------------------------------------
@@ -1182,7 +1210,7 @@ void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u
                    int row_lo, int row_hi, float dt0, int b)
 {
     if (row_hi <= row_lo) return;
-    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_advect<S>, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s, (S*)d,
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_advect<S>, dim3(cdiv(cdiv(n, 4), 256), row_hi - row_lo), dim3(256), 0, s, (S*)d,
                                             (const S*)d0, (const S*)u, (const S*)v, pitch, n, row_lo, row_hi, dt0, b));
 }
 
@@ -1190,7 +1218,7 @@ void launch_advect2(hipStream_t s, int st, void* da, const void* d0a, int ba, vo
                     const void* v, int pitch, int n, int row_lo, int row_hi, float dt0)
 {
     if (row_hi <= row_lo) return;
-    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_advect2<S>, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s, (S*)da,
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_advect2<S>, dim3(cdiv(cdiv(n, 4), 256), row_hi - row_lo), dim3(256), 0, s, (S*)da,
                                             (const S*)d0a, ba, (S*)db, (const S*)d0b, bb, (const S*)u, (const S*)v, pitch, n,
                                             row_lo, row_hi, dt0));
 }
