@@ -46,6 +46,8 @@ void launch_divergence(hipStream_t s, int st, const void* u, const void* v, void
                        int row_lo, int row_hi, float h, int write_p);
 void launch_subtract_gradient(hipStream_t s, int st, void* u, void* v, const void* p, int pitch, int n, int row_lo,
                               int row_hi, float h);
+void launch_gradient_advect(hipStream_t s, int st, void* u, void* v, const void* p, void* d, const void* d0, int pitch, int n,
+                            int row_lo, int row_hi, float h, float dt0, int b);
 void launch_absmax2(hipStream_t s, int st, const void* u, const void* v, int pitch, int n, int row_lo, int row_hi,
                     unsigned int* result);
 void launch_residual(hipStream_t s, int st, const void* x, const void* x0, int pitch, int n, int row_lo, int row_hi,

@@ -1024,6 +1024,48 @@ __global__ __launch_bounds__(256) void k_subtract_gradient(S* __restrict__ u, S*
     emit_ghosts(v, P, n, 2, j, i, nv);
 }
 
+// The last two operators of a step in one pass (FluidSequential.c:240 + :185): the gradient subtraction
+// of the second projection, then the density advection along the velocity it has just produced.  The
+// back-trace of cell (i, j) needs u and v at (i, j) only -- the values this thread holds in registers
+// (as stored: rounded to the storage type first) -- so the advection need not read the two fields back.
+// Four cells per thread, per cell the arithmetic of k_subtract_gradient and k_advect.
+template <typename S>
+__device__ __forceinline__ float as_stored(float v)
+{
+    if constexpr (sizeof(S) == 2) return keep_f32((float)(S)keep_f32(v));
+    else return v;
+}
+
+template <typename S>
+__global__ __launch_bounds__(256) void k_gradient_advect(S* __restrict__ u, S* __restrict__ v, const S* __restrict__ p,
+                                                         S* __restrict__ d, const S* __restrict__ d0, int pitch, int n,
+                                                         int row_lo, int row_hi, float h, float dt0, int b)
+{
+    const int j = 1 + 4 * (blockIdx.x * 256 + threadIdx.x);
+    const int i = row_lo + blockIdx.y;
+    if (j > n || i >= row_hi) return;
+    const size_t P = (size_t)pitch;
+    const size_t c = (size_t)i * P + XOFF + j;
+    const float4 pm = ld4(p + c), pu = ld4(p + c - P), pd = ld4(p + c + P), u4 = ld4(u + c), v4 = ld4(v + c);
+    const float pw[6] = {ld1(p + c - 1), pm.x, pm.y, pm.z, pm.w, ld1(p + c + 4)};     // columns j-1 .. j+4 of row i
+    const float up[4] = {pu.x, pu.y, pu.z, pu.w}, dn[4] = {pd.x, pd.y, pd.z, pd.w};
+    const float uo[4] = {u4.x, u4.y, u4.z, u4.w}, vo[4] = {v4.x, v4.y, v4.z, v4.w};
+    float nu[4], nv[4], val[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float gx = 0.5f * (pw[k + 2] - pw[k]);
+        const float gy = 0.5f * (dn[k] - up[k]);
+        nu[k] = uo[k] - gx / h;
+        nv[k] = vo[k] - gy / h;
+    }
+    advect_store(u, P, n, 1, j, i, nu);
+    advect_store(v, P, n, 2, j, i, nv);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        val[k] = advect_sample(d0, P, advect_trace(j + k, i, as_stored<S>(nu[k]), as_stored<S>(nv[k]), dt0, n, P));
+    advect_store(d, P, n, b, j, i, val);
+}
+
 // ---------------------------------------------------------------------------
 // wavefront reductions (diagnostics + the advect halo bound of the slab path).
 // 64-lane __shfl_xor butterflies, one atomic per wave.  Neither feeds back
@@ -1238,6 +1280,14 @@ void launch_subtract_gradient(hipStream_t s, int st, void* u, void* v, const voi
     if (row_hi <= row_lo) return;
     FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_subtract_gradient<S>, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s,
                                             (S*)u, (S*)v, (const S*)p, pitch, n, row_lo, row_hi, h));
+}
+
+void launch_gradient_advect(hipStream_t s, int st, void* u, void* v, const void* p, void* d, const void* d0, int pitch, int n,
+                            int row_lo, int row_hi, float h, float dt0, int b)
+{
+    if (row_hi <= row_lo) return;
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_gradient_advect<S>, dim3(cdiv(cdiv(n, 4), 256), row_hi - row_lo), dim3(256), 0, s,
+                                            (S*)u, (S*)v, (const S*)p, (S*)d, (const S*)d0, pitch, n, row_lo, row_hi, h, dt0, b));
 }
 
 void launch_absmax2(hipStream_t s, int st, const void* u, const void* v, int pitch, int n, int row_lo, int row_hi,

@@ -663,6 +663,27 @@ int op_subtract_gradient(fluid_ctx* c, int u, int v, int p)
     return FLUID_OK;
 }
 
+// the gradient subtraction of a projection and the advection of `d` (from d0, wall rule b) along the projected velocity,
+// in one launch: results identical to op_subtract_gradient followed by op_advect.  One GPU only (on slabs the advection
+// waits for a reduction over the velocity it follows).
+int op_gradient_advect(fluid_ctx* c, int u, int v, int p, int b, int d, int d0, float dt)
+{
+    if (p == u || p == v || u == v) return fail(FLUID_E_INVALID, "subtract_gradient: fields must be distinct");
+    if (d == d0 || d == u || d == v || d == p || d0 == u || d0 == v)
+        return fail(FLUID_E_INVALID, "advect: output must not alias an input");
+    if (c->nranks != 1) return fail(FLUID_E_INVALID, "op_gradient_advect is a one-GPU operator");
+    const float h = 1.0f / (float)c->n;
+    TRY(materialize(c, {u, v, p, d0}));
+    c->zero[d] = false;
+    TIMED(c, FLUID_TIME_PROJECTION,
+          fluid::launch_gradient_advect(c->stream, c->st, c->f[u], c->f[v], c->f[p], c->f[d], c->f[d0], c->pitch, c->n, c->own0,
+                                        c->own1, h, dt * (float)c->n, b));
+    wrote(c, u, 0);
+    wrote(c, v, 0);
+    wrote(c, d, 0);
+    return FLUID_OK;
+}
+
 void coefficients(int n, float dt, float coef, float* alpha, float* beta)
 {
     // ((dt*coef)*n)*n in float, then 1 + 4*alpha (FluidSequential.c:179-180,199-200)
@@ -677,13 +698,20 @@ void coefficients(int n, float dt, float coef, float* alpha, float* beta)
 // divergence -> pressure solve -> gradient subtraction (FluidSequential.c:213-223
 // and :238-240).  On slabs: ONE exchange (u, v, iters+2 rows) covers the divergence,
 // every sweep of the solve and the gradient's one-row halo of p.
-int project(fluid_ctx* c, int u, int v, int p, int div, int iters)
+// `then_advect` (one GPU): d, d0, b, dt of an advection along (u, v) to run in the same launch as the gradient subtraction
+struct AdvectAfter {
+    int b, d, d0;
+    float dt;
+};
+
+int project(fluid_ctx* c, int u, int v, int p, int div, int iters, const AdvectAfter* then_advect = nullptr)
 {
     TRY(op_divergence(c, u, v, p, div, std::min(iters, c->halo - 1)));
     c->in_pressure_solve = true;            // timing only: reported separately (fluid_timing::pressure_ms)
     const int rc_solve = op_diffuse(c, 0, p, div, 1.0f, 4.0f, iters, /*final_reach=*/1);
     c->in_pressure_solve = false;
     TRY(rc_solve);
+    if (then_advect) return op_gradient_advect(c, u, v, p, then_advect->b, then_advect->d, then_advect->d0, then_advect->dt);
     return op_subtract_gradient(c, u, v, p);
 }
 
@@ -742,8 +770,8 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
         TRY(op_diffuse_batch(c, all, 3, iters));
         TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
         TRY(op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt));
-        TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters));
-        return op_advect(c, 0, D, D0, U, V, dt);
+        const AdvectAfter dens{0, D, D0, dt};
+        return project(c, U, V, /*p=*/U0, /*div=*/V0, iters, &dens);
     }
     // Slabs: each advect needs the global max |velocity| on the host -- a pipeline drain.  The
     // density diffusion depends on nothing in between, so most of it rides in the same launches as

@@ -88,11 +88,12 @@ def test_timing_categories_count_every_operator():
         s.step(2)
         t = s.timing_read()
         # per step: 5 solves = 200 sweeps (the 3 diffusions run as one batch call, the 2 pressure solves
-        # on their own), 2 divergence, 2 gradient, 3 advections in 2 launches (u and v share one,
-        # SURVEY.md 3.1).  add_source: 3 kernels in the step that has sources; once the sources are
-        # zero (FluidSequential.c:298-302) x + dt*0 rides in the solve's load of its right-hand side.
+        # on their own), 2 divergence, 2 gradient, 3 advections in 1 launch of their own (u and v share
+        # it; the density's rides in the second gradient launch).  add_source: 3 kernels
+        # in the step that has sources; once the sources are zero (FluidSequential.c:298-302) x + dt*0
+        # rides in the solve's load of its right-hand side.
         assert (t["source_calls"], t["solves"], t["sweeps"]) == (3, 9, 600)
-        assert (t["divergence_calls"], t["projection_calls"], t["advection_calls"]) == (6, 6, 6)
+        assert (t["divergence_calls"], t["projection_calls"], t["advection_calls"]) == (6, 6, 3)
         assert all(t[k + "_ms"] > 0 for k in ("source", "diffusion", "divergence", "projection", "advection"))
         s.timing_enable(False)
         r = run_steps(s, 3, first_uses_sources=False)
