@@ -172,6 +172,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(a.backend)
+        # the first operation on a NCCL group must be one every rank takes part in (batched send/recv as
+        # the first call is undefined otherwise); it also gets RCCL's lazy set-up out of the way
+        hello = torch.ones(1, device="cuda" if a.backend == "nccl" else "cpu")
+        dist.all_reduce(hello)
+        assert int(hello.item()) == world
     from fluidsimulationcuda_amd.harness import initialize_parameters
     from fluidsimulationcuda_amd.slab import SlabSolver
 

@@ -177,6 +177,11 @@ class SlabSolver(FluidSolver):
                        for k in range(capi.NFIELDS)]
         self.exchange = None
         if nranks > 1:
+            if dist.get_backend(group) == "nccl":
+                # batched send/recv must not be the first operation on a NCCL group: start with an all-reduce
+                hello = torch.ones(1, device=self.device)
+                dist.all_reduce(hello, group=group)
+                torch.cuda.synchronize(self.device)
             self.exchange = TorchExchange(self.field_tensor, n, rank, nranks, group, stream=self.torch_stream)
             off = self.scalar_ptr() - self.arena.data_ptr()
             self.exchange.scalar = self.arena[off:off + 4].view(torch.float32)
