@@ -113,6 +113,37 @@ def test_steps_through_the_fused_kernel_on_signed_zero_fields(F, oracle, n, lane
         assert_bit_equal(s.download("v_prev"), v0, "vel_step leaves the divergence in v_prev")
 
 
+@pytest.mark.parametrize("n", [254, 510])
+def test_decay_through_the_denormal_range_matches_oracle(F, oracle, n):
+    """With the sources zeroed after step 0 (FluidSequential.c:298-302) every solve restarts from a zero
+    first guess and the fields shrink by orders of magnitude per step: within a few steps they hold
+    tiny (< 2^-100) and denormal values, and die out entirely after ~20.  Re-inject sources every
+    four steps so the run keeps crossing that whole range, and demand the oracle's bits throughout
+    (the fused kernel's division shortcuts are exact there only because they were chosen to be)."""
+    from fluidsimulationcuda_amd import capi
+    from fluidsimulationcuda_amd.harness import initialize_parameters
+    z = np.zeros((n + 2, n + 2), np.float32)
+    u, v, dens = z.copy(), z.copy(), z.copy()
+    tiny_seen = denormal_seen = 0
+    with F.FluidSolver(n, params={capi.PARAM_TB_MIN_CELLS: 0}) as s:
+        s.upload(u=u, v=v, dens=dens)
+        for k in range(3):
+            f = initialize_parameters(n, seed=20 + k)
+            u0, v0, d0 = f["u_prev"].copy(), f["v_prev"].copy(), f["dens_prev"].copy()
+            s.upload(u_prev=u0, v_prev=v0, dens_prev=d0)
+            s.step(1, use_sources=True)
+            oracle.step_src(u, v, dens, u0, v0, d0)
+            for _ in range(3):
+                s.step(1)
+                oracle.step(u, v, dens, u0, v0, d0)
+            for name, want in (("u", u), ("v", v), ("dens", dens), ("u_prev", u0), ("v_prev", v0), ("dens_prev", d0)):
+                assert_bit_equal(s.download(name), want, "%s after round %d, n=%d" % (name, k, n))
+            a = np.abs(dens)
+            tiny_seen += int(((a < 2.0 ** -100) & (a > 0)).sum())
+            denormal_seen += int(((a < 2.0 ** -126) & (a > 0)).sum())
+    assert tiny_seen > 0 and denormal_seen > 0, "the run was meant to cross the tiny and denormal ranges"
+
+
 def _fnv1a(a):
     hv, pv, mask = 0xCBF29CE484222325, 0x100000001B3, (1 << 64) - 1
     for x in np.ascontiguousarray(a).view(np.uint32).ravel().tolist():
