@@ -48,7 +48,9 @@ enum {
  * blocked: up to 16 sweeps per launch, same bits as that many single-sweep launches. */
 enum { FLUID_JACOBI_STREAM = 0, FLUID_JACOBI_LDS = 1, FLUID_JACOBI_NAIVE = 2, FLUID_JACOBI_TB = 3 };
 
-/* Tuning knobs for fluid_set_param(); none of them changes results. */
+/* Tuning knobs for fluid_set_param(); none of them changes results with FLUID_STORAGE_F32.  (With FLUID_STORAGE_F16
+ * a fused launch rounds once when it stores, so the launch schedule -- TB_MAX_SWEEPS, TB_MIN_CELLS -- is part of the
+ * result there; all other knobs are speed only in both storage types.) */
 enum {
     FLUID_PARAM_TB_MAX_SWEEPS = 0, /* most sweeps fused per launch by FLUID_JACOBI_TB: 16 (default), 8, 4 or 2 */
     FLUID_PARAM_TB_ROWS = 1,       /* output rows per wave strip of FLUID_JACOBI_TB; 0 = auto          */
