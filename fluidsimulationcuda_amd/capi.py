@@ -17,6 +17,7 @@ JACOBI_STREAM, JACOBI_LDS, JACOBI_NAIVE, JACOBI_TB = 0, 1, 2, 3
 STORAGE_F32, STORAGE_F16 = 0, 1
 PARAM_TB_MAX_SWEEPS, PARAM_TB_ROWS, PARAM_HALO, PARAM_TB_FAST_DIVISION, PARAM_TB_MIN_CELLS, PARAM_TB_EDGE_ROWS_PCT = 0, 1, 2, 3, 4, 5
 PARAM_TB_LANE_COLUMNS = 6
+PARAM_TB_T16_MIN_CELLS = 7
 XCHG_HALO, XCHG_GATHER, XCHG_MAX, XCHG_MAX_BEGIN, XCHG_MAX_END = 0, 1, 2, 3, 4
 FIELD_NAMES = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev", "tmp0", "tmp1", "tmp2")
 

@@ -48,7 +48,8 @@ int fail(int code, const char* fmt, ...)
     } while (0)
 
 constexpr size_t kControlBytes = 256;   // tail of the arena: reduction scalar (+0), division-proof counter (+8)
-constexpr int kMaxN = 1 << 20;   // index arithmetic is size_t; advect's clamp constant needs N < 2^23
+constexpr int kMaxN = 65533;     // one grid row per blockIdx.y in the pointwise kernels (HIP: gridDim.y <= 65535 = N + 2);
+                                 // 65535^2 x 9 fields is 155 GB of the 288 GB, so nothing practical is cut off
 
 }  // namespace
 
@@ -69,6 +70,8 @@ struct fluid_ctx {
     int variant = fluid::JACOBI_TB;
     int tb_max_t = 16, tb_rows = 0, num_cu = 256;   // temporal blocking: sweeps/launch cap, rows/strip (0 = auto)
     long long tb_min_cells = 0;                    // smaller slabs use single-sweep launches (never faster since the 2-column lanes)
+    long long tb_t16_min_cells = -1;               // >= 0: 16-sweep launches on every slab of at least this many cells (tests, tuning);
+                                                   // -1: the measured rule of pick_sweeps()
     bool defer_zero_source = true;                 // see settle()
     bool in_halo_exchange = false;
     int tb_nv = 2;                                 // columns per lane of the fused kernel (2: 4 waves/SIMD; 4: 2 waves/SIMD)
@@ -362,6 +365,31 @@ int op_add_source(fluid_ctx* c, int x, int s, float dt)
     return FLUID_OK;
 }
 
+// Sweeps fused into the next launch of a solve that has `room` sweeps it can still run (remaining sweeps,
+// and on slabs the valid reach).  Greedy: the deepest launch that fits.
+int pick_sweeps(const fluid_ctx* c, int room, bool canonical, bool small, long long slab_cells, bool all_mode4)
+{
+    // the fused kernel addresses a field through 32-bit buffer offsets: fields of 2 GiB and more
+    // (beyond ~23000^2 in fp32) take single-sweep launches
+    if (c->variant != fluid::JACOBI_TB || small || c->field_bytes >= 0x7F000000ull) return 1;
+    // 16 sweeps per launch exist for 2-column lanes and fp32 storage (fp16 results depend on the
+    // launch schedule, which stays the 8-sweep one)
+    // -- where they pay: the pressure form (a packed multiply per pair) is bound by memory at every
+    // size; the general form (a double-precision multiply per cell) is bound by arithmetic, which
+    // deeper blocking only adds to, until the fields outgrow the 256 MB Infinity Cache.  Grids (or slabs)
+    // under 8 M cells do not have the rows to fill the chip with 16-sweep strips (measured: 8 wins up to 3072^2).
+    // FLUID_PARAM_TB_T16_MIN_CELLS replaces both size rules by one floor (0: always), so that tests can
+    // run the 16-sweep kernels of either form on grids the oracle finishes in milliseconds.
+    if (room >= 16 && c->tb_max_t >= 16 && c->tb_nv == 2 && !canonical) {
+        const bool pays = c->tb_t16_min_cells >= 0
+                              ? slab_cells >= c->tb_t16_min_cells
+                              : slab_cells >= (8ll << 20) &&
+                                    (all_mode4 || (unsigned long long)slab_cells * c->esz > (96ull << 20));
+        if (pays) return 16;
+    }
+    return (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
+}
+
 // One Jacobi solve of the step: field x (first guess in, result out), right-hand
 // side x0, wall rule b.  Up to three such solves of the same length run as one
 // batch (u, v and density diffusion are independent of one another).
@@ -431,21 +459,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
     const bool small = (canonical ? (long long)c->n * c->n : slab_cells * count) < c->tb_min_cells;
     for (int k = 0; k < iters;) {
         const int remaining = iters - k;
-        auto pick = [&](int room) {
-            // the fused kernel addresses a field through 32-bit buffer offsets: fields of 2 GiB and more
-            // (beyond ~23000^2 in fp32) take single-sweep launches
-            if (c->variant != fluid::JACOBI_TB || small || c->field_bytes >= 0x7F000000ull) return 1;
-            // 16 sweeps per launch exist for 2-column lanes and fp32 storage (fp16 results depend on the
-            // launch schedule, which stays the 8-sweep one)
-            // -- where they pay: the pressure form (a packed multiply per pair) is bound by memory at every
-            // size; the general form (a double-precision multiply per cell) is bound by arithmetic, which
-            // deeper blocking only adds to, until the fields outgrow the 256 MB Infinity Cache.  Grids (or slabs)
-            // under 8 M cells do not have the rows to fill the chip with 16-sweep strips (measured: 8 wins up to 3072^2).
-            if (room >= 16 && c->tb_max_t >= 16 && c->tb_nv == 2 && !canonical && slab_cells >= (8ll << 20) &&
-                (all_mode4 || (unsigned long long)slab_cells * c->esz > (96ull << 20)))
-                return 16;
-            return (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
-        };
+        auto pick = [&](int room) { return pick_sweeps(c, room, canonical, small, slab_cells, all_mode4); };
         const int wantT = canonical ? pick(remaining) : 1;     // slabs with fp16 storage keep halo >= 8 (fluid_create_ex)
         if (r < wantT) {
             const int depth = std::max(wantT, std::min(c->halo, remaining + final_reach));
@@ -778,8 +792,28 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
     // u and v (the fused kernel is latency-bound: a third field per launch is nearly free) and its
     // last sweeps are held back, one launch behind each reduction, so the GPU stays busy while the
     // host waits and talks to its peers.
-    const int rest = std::min(iters, 16), head = iters - rest;          // multiples of 8 for iters = 40
-    const int fill1 = std::min(rest, 8), fill2 = rest - fill1;
+    // The split falls on launch boundaries of the solve's own schedule (the last two launches are the ones
+    // held back): with fp16 storage every launch rounds once, so cutting a launch in two would change the
+    // result (iters = 20 runs as 8 + 8 + 4 on one GPU and must do so here).
+    int fill1 = 0, fill2 = 0;
+    {
+        const bool canonical = c->st == fluid::STORAGE_F16;
+        const long long slab_cells = (long long)c->min_slab * c->n;
+        const bool small = (canonical ? (long long)c->n * c->n : slab_cells) < c->tb_min_cells;
+        std::vector<int> launches;
+        for (int left = iters; left > 0;) {
+            launches.push_back(pick_sweeps(c, left, canonical, small, slab_cells, /*all_mode4=*/false));
+            left -= launches.back();
+        }
+        // about eight sweeps behind each reduction (whole launches; single-sweep kernels: eight launches)
+        for (int* fill : {&fill2, &fill1})
+            while (*fill < 8 && !launches.empty()) {
+                *fill += launches.back();
+                launches.pop_back();
+            }
+        if (fill1 == 0) std::swap(fill1, fill2);
+    }
+    const int rest = fill1 + fill2, head = iters - rest;
     if (head > 0) TRY(op_diffuse_batch(c, all, 3, head));
     if (rest > 0) TRY(op_diffuse_batch(c, all, 2, rest));
     TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
@@ -1094,6 +1128,10 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
         return FLUID_OK;
     case FLUID_PARAM_TB_FAST_DIVISION:
         c->fast_div = value != 0;
+        return FLUID_OK;
+    case FLUID_PARAM_TB_T16_MIN_CELLS:
+        if (value < -1) return fail(FLUID_E_INVALID, "TB_T16_MIN_CELLS must be >= 0, or -1 for the default rule");
+        c->tb_t16_min_cells = value;
         return FLUID_OK;
     case FLUID_PARAM_TB_LANE_COLUMNS:
         if (value != 2 && value != 4) return fail(FLUID_E_INVALID, "TB_LANE_COLUMNS must be 2 or 4");

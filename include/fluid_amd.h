@@ -63,6 +63,9 @@ enum {
                                       the interior windows' (default 40; 0 = same): load balance only  */
     ,FLUID_PARAM_TB_LANE_COLUMNS = 6 /* columns per lane of FLUID_JACOBI_TB: 2 (default; thin waves, 4 per SIMD)
                                       or 4 (2 per SIMD): speed only                                      */
+    ,FLUID_PARAM_TB_T16_MIN_CELLS = 7 /* 16-sweep launches (fp32 storage, 2-column lanes) on slabs of at least this many
+                                      cells, for either form of the solve; -1 (default): the measured rule -- from
+                                      8 M cells, the general form only once a field outgrows 96 MiB     */
     ,FLUID_PARAM_TB_MIN_CELLS = 4  /* FLUID_JACOBI_TB fuses sweeps only on slabs of at least this many cells
                                       (default 0: always); smaller ones run one-thread-per-cell sweeps   */
 };

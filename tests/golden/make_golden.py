@@ -128,18 +128,24 @@ def full_steps(n, iters=40, steps=(1, 2, 5)):
 
 
 def checksums():
-    """Too big to commit as arrays: FNV-1a + float64 sums of step 1 from the
-    reference's own initializeParameters (glibc rand, seed 1)."""
+    """Too big to commit as arrays: CRC-32 of the bytes + float64 sums of step 1 from the
+    reference's own initializeParameters (glibc rand, seed 1); FNV-1a too where the
+    pure-python hash is affordable."""
+    import zlib
     rows = []
-    for n in (254, 1022, 4094):
+    for n in (254, 1022, 4094, 8190):
         r = Reference(n, 40)
         dens, dens0, u, u0, v, v0 = r.initialize(seed=1)
         r.step_src(u, v, dens, u0, v0, dens0)
         c = (n + 2) // 2
-        rows.append(dict(n=n, fnv_u=fnv1a(u), fnv_v=fnv1a(v), fnv_dens=fnv1a(dens),
-                         sum_u=float(u.sum(dtype=np.float64)), sum_v=float(v.sum(dtype=np.float64)),
-                         sum_dens=float(dens.sum(dtype=np.float64)),
-                         u_c=float(u[c, c]), dens_c=float(dens[c, c])))
+        row = dict(n=n, crc_u=zlib.crc32(u.view(np.uint8).reshape(-1)), crc_v=zlib.crc32(v.view(np.uint8).reshape(-1)),
+                   crc_dens=zlib.crc32(dens.view(np.uint8).reshape(-1)),
+                   sum_u=float(u.sum(dtype=np.float64)), sum_v=float(v.sum(dtype=np.float64)),
+                   sum_dens=float(dens.sum(dtype=np.float64)),
+                   u_c=float(u[c, c]), dens_c=float(dens[c, c]))
+        if n <= 1022:
+            row.update(fnv_u=fnv1a(u), fnv_v=fnv1a(v), fnv_dens=fnv1a(dens))
+        rows.append(row)
         print(rows[-1])
     import json
     with open(os.path.join(OUT, "checksums.json"), "w") as f:
@@ -147,6 +153,9 @@ def checksums():
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["checksums"]:
+        checksums()
+        sys.exit(0)
     for n in (14, 30, 61):
         operators(n)
     for n in (30, 61, 126):

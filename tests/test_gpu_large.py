@@ -1,0 +1,140 @@
+"""GPU: BASELINE configs 3 and 4 at their own sizes -- 8192^2 (fp32, one context and row slabs) and
+16384^2 (fp16 storage) -- against the oracle itself, not against another HIP path.  These sizes select
+kernels no smaller grid reaches by default: 16-sweep fused launches of the general (diffusion) form need a
+field of more than 96 MiB.  Every test asserts the launch schedule it means to exercise.
+
+CPU cost (one host core): a 40-sweep solve at 8192^2 ~2-3 s, a full step ~12 s; 16 sweeps at 16384^2 ~4 s."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_bit_equal, rnd
+
+pytestmark = pytest.mark.gpu
+DT, VISC, DIFF = 0.016, 0.0025, 0.1
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fluidsimulationcuda_amd as F
+    return F
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a, dtype=np.float32).view(np.uint8).reshape(-1))
+
+
+@pytest.mark.parametrize("form", ["pressure", "viscosity", "density"])
+def test_40_sweep_solve_at_8192_matches_oracle(F, oracle, form):
+    """FluidSequential.c:85-104 at N = 8190: the default schedule is 16 + 16 + 8 sweeps per launch for both
+    forms (k_jacobi_tb<16,4,2> / <16,2,2> and the <8,...> remainder)."""
+    n = 8190
+    rng = np.random.default_rng({"pressure": 1, "viscosity": 2, "density": 3}[form])
+    b, (alpha, beta) = {"pressure": (0, (1.0, 4.0)), "viscosity": (1, F.coefficients(n, DT, VISC)),
+                        "density": (0, F.coefficients(n, DT, DIFF))}[form]
+    x, x0 = rnd(rng, n), rnd(rng, n)
+    with F.FluidSolver(n) as s:
+        s.upload(u=x, v=x0)
+        s.timing_enable(True)
+        s.timing_read(reset=True)
+        s.diffuse(b, "u", "v", alpha, beta, 40)
+        t = s.timing_read(reset=True)
+        got = s.download("u")
+    assert t["jacobi_launches"] == 3 and t["sweeps"] == 40, "expected 16 + 16 + 8 sweeps, got %r" % (t,)
+    oracle.diffuse(b, x, x0, alpha, beta, 40)
+    assert_bit_equal(got, x, "40-sweep %s solve at 8192^2" % form)
+
+
+def test_true_division_16_sweep_kernel_at_8192_matches_oracle(F, oracle):
+    """k_jacobi_tb<16,0,2>: the general form with FAST_DIVISION off (the fallback every beta that fails the
+    on-device proof takes)."""
+    from fluidsimulationcuda_amd import capi
+    n = 8190
+    rng = np.random.default_rng(4)
+    alpha, beta = F.coefficients(n, DT, VISC)
+    x, x0 = rnd(rng, n), rnd(rng, n)
+    with F.FluidSolver(n, params={capi.PARAM_TB_FAST_DIVISION: 0}) as s:
+        s.upload(u=x, v=x0)
+        s.timing_enable(True)
+        s.timing_read(reset=True)
+        s.diffuse(2, "u", "v", alpha, beta, 16)
+        t = s.timing_read(reset=True)
+        got = s.download("u")
+    assert t["jacobi_launches"] == 1
+    oracle.diffuse(2, x, x0, alpha, beta, 16)
+    assert_bit_equal(got, x, "16 sweeps, true division, 8192^2")
+
+
+def test_two_steps_at_8192_match_oracle_and_two_slabs(F, oracle):
+    """BASELINE config 3's grid: step_src + step (FluidSequential.c:298-306) in one context against the
+    oracle, all six fields; then the same two steps on two row slabs (in-process fabric, one GPU) against
+    that -- the slab kernels at the size they are meant for."""
+    from test_gpu_slab import run_ranks
+    from fluidsimulationcuda_amd.harness import initialize_parameters
+    n = 8190
+    f = initialize_parameters(n, seed=3)
+
+    def body(s):
+        s.step(1, use_sources=True)
+        s.step(1)
+
+    with F.FluidSolver(n) as s:
+        s.upload(**f)
+        s.timing_enable(True)
+        body(s)
+        t = s.timing_read()
+        one = {k: s.download(k) for k in ("u", "v", "dens", "u_prev", "v_prev", "dens_prev")}
+    # per step: the three diffusions share launches (16+16+8), each projection has its own 16+16+8
+    assert t["jacobi_launches"] == 2 * 9 and t["sweeps"] == 2 * 200, t
+    got, fab = run_ranks(n, 2, 0, f, body, jacobi=3)
+    for k in ("u", "v", "dens"):
+        assert_bit_equal(got[k], one[k], "%s: 2 slabs vs one context at 8192^2" % k)
+    assert fab.log[1] == fab.log[0]
+    del got
+    w = {k: v.copy() for k, v in f.items()}
+    oracle.step_src(w["u"], w["v"], w["dens"], w["u_prev"], w["v_prev"], w["dens_prev"])
+    oracle.step(w["u"], w["v"], w["dens"], w["u_prev"], w["v_prev"], w["dens_prev"])
+    for k in ("u", "v", "dens", "u_prev", "v_prev", "dens_prev"):
+        assert_bit_equal(one[k], w[k], "%s after two steps at 8192^2" % k)
+
+
+@pytest.mark.parametrize("n", [1022, 4094, 8190])
+def test_reference_crc_at_full_size(F, n):
+    """Step 1 from the reference's own initializeParameters (glibc rand, seed 1): CRC-32 of the bytes of u, v
+    and dens as the compiled reference left them (tests/golden/checksums.json, make_golden.py)."""
+    from oracle.oracle import Oracle
+    row = [r for r in json.load(open(os.path.join(GOLDEN, "checksums.json"))) if r["n"] == n][0]
+    dens, dens0, u, u0, v, v0 = Oracle().initialize_glibc(n, seed=1)
+    with F.FluidSolver(n) as s:
+        s.upload(u=u, v=v, dens=dens, u_prev=u0, v_prev=v0, dens_prev=dens0)
+        s.step(1, use_sources=True)
+        gu, gv, gd = s.download("u"), s.download("v"), s.download("dens")
+    assert (crc(gu), crc(gv), crc(gd)) == (row["crc_u"], row["crc_v"], row["crc_dens"])
+
+
+def test_fp16_fused_launches_at_16384_match_rounded_oracle(F, oracle):
+    """BASELINE config 4's grid (fp16 fields, fp32 accumulate): two fused launches of 8 sweeps of the
+    density-diffusion form at N = 16382 against the oracle's fp32 sweeps with one numpy.float16 rounding
+    per launch (the parity recipe of test_gpu_f16.py)."""
+    from fluidsimulationcuda_amd import capi
+    from test_gpu_f16 import emu_solve, h
+    n = 16382
+    rng = np.random.default_rng(16)
+    alpha, beta = F.coefficients(n, DT, DIFF)
+    x = rng.random((n + 2, n + 2), dtype=np.float32) - np.float32(0.5)
+    x0 = rng.random((n + 2, n + 2), dtype=np.float32) - np.float32(0.5)
+    with F.FluidSolver(n, storage=capi.STORAGE_F16) as s:
+        s.upload(u=x, v=x0)
+        s.timing_enable(True)
+        s.timing_read(reset=True)
+        s.diffuse(0, "u", "v", alpha, beta, 16)
+        t = s.timing_read(reset=True)
+        got = s.download("u")
+    assert t["jacobi_launches"] == 2
+    want = emu_solve(oracle, 0, x, x0, alpha, beta, [8, 8])
+    del x, x0
+    assert_bit_equal(got, want, "fp16 storage, 8 + 8 sweeps at 16384^2")
+    assert_bit_equal(got, h(got), "stored values are fp16")

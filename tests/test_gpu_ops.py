@@ -211,22 +211,46 @@ TB_SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 14, 61, 64, 95, 96, 97, 111, 112, 113, 119, 
             223, 224, 225, 239, 240, 241, 247, 248, 249, 255, 256, 257, 480, 481, 1022]
 
 
-@pytest.mark.parametrize("lane_cols,max_t", [(2, 16), (2, 8), (2, 4), (2, 2), (4, 8), (4, 4), (4, 2)])
+def tb_schedule(iters, max_t):
+    """launch depths of one solve: greedy, deepest first (fluid_solver.hip: pick_sweeps)"""
+    out = []
+    while iters:
+        t = next(t for t in (16, 8, 4, 2) if t <= min(max_t, iters))
+        out.append(t)
+        iters -= t
+    return out
+
+
+@pytest.mark.parametrize("lane_cols,max_t,fast_div", [(2, 16, 1), (2, 16, 0), (2, 8, 1), (2, 4, 1), (2, 2, 1), (4, 8, 1),
+                                                      (4, 4, 1), (4, 2, 1)])
 @pytest.mark.parametrize("n", TB_SIZES)
-def test_temporal_blocking_matches_oracle(F, oracle, n, lane_cols, max_t):
+def test_temporal_blocking_matches_oracle(F, oracle, n, lane_cols, max_t, fast_div):
+    """Every depth of the fused kernel, both forms (pressure: alpha 1, beta 4; general: the exact
+    reciprocal division, or true division with fast_div = 0), on window / strip / wall edge sizes.
+    The launch count is asserted so that a silently shallower schedule fails: 16-sweep launches are
+    normally reserved for grids of 8 M cells and more (PARAM_TB_T16_MIN_CELLS forces them here)."""
     from fluidsimulationcuda_amd import capi
     rng = np.random.default_rng(500 + n)
     with F.FluidSolver(n, jacobi=capi.JACOBI_TB) as s:
         s.set_param(capi.PARAM_TB_MIN_CELLS, 0)              # fuse sweeps even on these small grids
+        s.set_param(capi.PARAM_TB_T16_MIN_CELLS, 0)          # ... 16 at a time where max_t allows
         s.set_param(capi.PARAM_TB_LANE_COLUMNS, lane_cols)
         s.set_param(capi.PARAM_TB_MAX_SWEEPS, max_t)
+        s.set_param(capi.PARAM_TB_FAST_DIVISION, fast_div)
+        s.timing_enable(True)
         for rows in (0, 1, 3, 16, 5000):
             s.set_param(capi.PARAM_TB_ROWS, rows)
             for b, (alpha, beta), iters in ((0, (1.0, 4.0), 40), (1, F.coefficients(n, DT, VISC), 22),
-                                            (2, F.coefficients(n, DT, DIFF), 6), (0, (0.7, 3.3), 8)):
+                                            (2, F.coefficients(n, DT, DIFF), 6), (0, (0.7, 3.3), 8),
+                                            (2, F.coefficients(n, DT, DIFF), 32)):
                 x, x0 = rnd(rng, n), rnd(rng, n)
                 s.upload(u=x, v=x0)
+                s.timing_read(reset=True)
                 s.diffuse(b, "u", "v", alpha, beta, iters)
+                t = s.timing_read(reset=True)
+                assert t["jacobi_launches"] == len(tb_schedule(iters, max_t)) and t["sweeps"] == iters, \
+                    "schedule %r expected for %d sweeps at max_t=%d, got %d launches" % (
+                        tb_schedule(iters, max_t), iters, max_t, t["jacobi_launches"])
                 want = x.copy()
                 oracle.diffuse(b, want, x0, alpha, beta, iters)
                 assert_bit_equal(s.download("u"), want,

@@ -271,17 +271,39 @@ def test_missing_exchange_callback_is_an_error():
         assert e.value.code == capi.E_COMM
 
 
+@pytest.mark.parametrize("iters", [40, 20, 28, 18, 6])
 @pytest.mark.parametrize("n,nranks,halo", [(254, 2, 0), (510, 4, 16), (257, 3, 5)])
-def test_fp16_storage_on_slabs_is_bit_identical_to_one_gpu(n, nranks, halo):
+def test_fp16_storage_on_slabs_is_bit_identical_to_one_gpu(n, nranks, halo, iters):
     """Same contract with fp16 fields: the slabs exchange half rows and fuse the
-    same launches per field, so they reproduce the single-context bits."""
+    same launches per field, so they reproduce the single-context bits.  With fp16 storage every launch
+    rounds once, so the schedule is part of the result: sweep counts whose schedule is not a row of
+    eights (20 = 8 + 8 + 4, 28, 18, 6) must be split for the slab path's overlap at launch boundaries."""
     fields = synthetic(n)
+
+    def body(s):
+        s.step(1, use_sources=True, iters=iters)
+        s.step(1, iters=iters)
+
+    want = single(n, fields, body, storage=1)
+    got, _ = run_ranks(n, nranks, halo, fields, body, jacobi=3, storage=1)
+    for k in ("u", "v", "dens"):
+        assert_bit_equal(got[k], want[k], "fp16 %s, %d slabs, %d sweeps" % (k, nranks, iters))
+
+
+@pytest.mark.parametrize("n,nranks,halo", [(254, 2, 0), (510, 4, 16), (1022, 2, 42)])
+def test_slabs_with_16_sweep_launches(n, nranks, halo):
+    """The slab path with 16-sweep launches forced on (they are the default only on slabs of 8 M cells and
+    more, which test_gpu_large.py runs once at 8192^2)."""
+    from fluidsimulationcuda_amd import capi
+    fields = synthetic(n, seed=9)
 
     def body(s):
         s.step(1, use_sources=True)
         s.step(1)
 
-    want = single(n, fields, body, storage=1)
-    got, _ = run_ranks(n, nranks, halo, fields, body, jacobi=3, storage=1)
+    want = single(n, fields, body)
+    got, fab = run_ranks(n, nranks, halo, fields, body, jacobi=3, params={capi.PARAM_TB_T16_MIN_CELLS: 0})
+    for r in range(1, nranks):
+        assert fab.log[r] == fab.log[0]
     for k in ("u", "v", "dens"):
-        assert_bit_equal(got[k], want[k], "fp16 %s, %d slabs" % (k, nranks))
+        assert_bit_equal(got[k], want[k], "%s, %d slabs, T=16 forced" % (k, nranks))

@@ -89,6 +89,13 @@ def test_checksums_survey_values(oracle):
     assert float(u.sum(dtype=np.float64)) == row["sum_u"]
     assert float(v.sum(dtype=np.float64)) == row["sum_v"]
     assert float(dens.sum(dtype=np.float64)) == row["sum_dens"]
+    import zlib
+    for n in (254, 1022):          # CRC-32 of the reference's bytes (the GPU tests pin 4094 and 8190 the same way)
+        row = [r for r in rows if r["n"] == n][0]
+        dens, dens0, u, u0, v, v0 = oracle.initialize_glibc(n, seed=1)
+        oracle.step_src(u, v, dens, u0, v0, dens0)
+        for name, a in (("u", u), ("v", v), ("dens", dens)):
+            assert zlib.crc32(a.view(np.uint8).reshape(-1)) == row["crc_" + name], "%s at N=%d" % (name, n)
     g = load_golden("step_n126_k40.npz")
     assert abs(float(g["s1_u"].sum(dtype=np.float64)) - 117.14561) < 1e-5
     assert abs(float(g["s1_dens"].sum(dtype=np.float64)) - 35.0967363) < 1e-6
