@@ -85,6 +85,7 @@ SIGNATURES = {
     "fluid_residual": [_ctx, _i, _i, _f, _f, C.POINTER(_f)],
     "fluid_absmax_velocity": [_ctx, _i, _i, C.POINTER(_f)],
     "fluid_set_jacobi_variant": [_ctx, _i],
+    "fluid_division_mode": [_ctx, _f, _f, C.POINTER(_i)],
     "fluid_set_param": [_ctx, _i, _i],
     "fluid_timing_enable": [_ctx, _i],
     "fluid_timing_read": [_ctx, C.POINTER(Timing), _i],

@@ -24,7 +24,11 @@ struct TbBatch {
     const void* x0[3];
     void* out[3];
     float alpha[3], beta[3];     // beta: divisor, or its exact reciprocal in division mode 4
-    double yd[3];                // RN64(1/beta) for division mode 2
+    double yd[3];                // RN64(1/beta) for division mode 2 (and mode 3's guarded steps)
+    float hi[3], lo[3];          // division mode 3: hi = RD32(1/beta), lo = RN32(1/beta - hi)
+    const unsigned* tiles[3];    // division mode 3: |x0| minima per tile (k_tile_min_abs), tile_pitch words per tile row
+    unsigned tile_thr[3];        //   ... and the bit pattern of beta * 2^-72 they must reach
+    int tile_pitch;
     int b[3];
     int x_zero[3];               // first guess known to be all +0: never read
     float x0_inc[3];             // added to every x0 value as it is loaded (-0.0f: nothing pending)
@@ -37,7 +41,16 @@ void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void
                    int row_lo, int row_hi, float alpha, float beta, int b);
 void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const TbBatch& batch, int pitch, int n, int row_lo,
                       int row_hi, int rb, int rb_edge);
-void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, double yd, unsigned long long* bad);
+// tiles of kTileRows x kTileCols interior cells, tile (r, c) = rows 1 + r*kTileRows.., columns 1 + c*kTileCols..
+constexpr int kTileRows = 32, kTileCols = 64;
+inline int tile_rows(int n) { return (n + kTileRows - 1) / kTileRows; }
+inline int tile_pitch(int n) { return (n + kTileCols - 1) / kTileCols; }
+struct TileBatch {
+    const void* field[3];
+    unsigned* tiles[3];
+};
+void launch_tile_min_abs(hipStream_t s, int st, const TileBatch& tb, int count, int pitch, int n, int row_lo, int row_hi, int tile_pitch);
+void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, double yd, float lo, unsigned long long* bad);
 void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u, const void* v, int pitch, int n,
                    int row_lo, int row_hi, float dt0, int b);
 void launch_advect2(hipStream_t s, int st, void* da, const void* d0a, int ba, void* db, const void* d0b, int bb, const void* u,

@@ -392,6 +392,18 @@ __global__ __launch_bounds__(256) void k_jacobi_stream(const S* __restrict__ x, 
 //   denormal midpoint, possible for a few even-integer-like beta -- is why the
 //   solver proves each beta on the device before using modes 2 and 4:
 //   k_validate_div compares them with a/beta for all 2^32 inputs.
+// 3: the two-term reciprocal q = fma(x, hi, x*lo) with hi = RD32(1/beta), lo = RN32(1/beta - hi) > 0 -- two
+//   PACKED instructions per pair of cells where mode 2 takes six scalar ones.  hi + lo carries 1/beta to
+//   ~2^-48 relative, which rounds like the true quotient for every x that is zero or at least beta * 2^-98 in
+//   magnitude (k_validate_div proves it for all such x; lo > 0 keeps -0 / beta = -0); below that x*lo loses bits
+//   to underflow and q can be one ulp off.  The dividends here are x0 + alpha*nb, and a float sum is either
+//   zero or no smaller than 2^-24 of its smaller operand, or than half its larger one: wherever the right-hand
+//   side x0 is at least m in magnitude, EVERY dividend of EVERY sweep is 0 or >= 2^-25 * m, whatever the
+//   neighbours hold.  So no per-value guard is needed, only a fact about x0: k_tile_min_abs reduces |x0| over
+//   tiles of kTileRows x kTileCols cells once per solve (x0 does not change during a solve), and a wave takes
+//   the two-term path if every tile its strip and window touch (overlaps included) is >= beta * 2^-72;
+//   otherwise, and in the windows and strips on the domain's edge, it divides as mode 2 does.  Velocities
+//   pass unless they have died out; a density with exact zeros outside its support falls back there.
 
 // One lane's share of a row: NV consecutive columns (NV = 2 or 4).
 template <int NV>
@@ -475,7 +487,9 @@ struct TbArgs {
     unsigned m_r[NV];     // all ones in the lane AND component that is ghost column n+1
     int n, q_lo, q_hi, cg;
     float alpha, beta;
-    double yd;            // DIVMODE 2: 1/beta rounded to double
+    double yd;            // DIVMODE 2 (and 3's fallback): 1/beta rounded to double
+    float lo;             // DIVMODE 3: lo = RN32(1/beta - hi); hi travels in `hi`
+    float hi;
     unsigned sx, sy;      // sign masks: flip across vertical / horizontal walls
     float x0_inc;         // pending add_source increment of the right-hand side (-0.0f: none)
     bool st_rg_lane, is_lg;
@@ -494,17 +508,21 @@ __device__ __forceinline__ Vec<NV> fxorv(const Vec<NV>& v, unsigned m)
 // (r + alpha*nb) / beta for one cell (the validator) and for a pair of cells (the kernel; same
 // operations, the compiler emits the packed form of each).
 template <int DIVMODE>
-__device__ __forceinline__ float tb_div(float num, float beta, double yd)
+__device__ __forceinline__ float tb_div(float num, float beta, double yd, float lo = 0.f)
 {
     if (DIVMODE == 0) return num / beta;
     if (DIVMODE == 4) return num * beta;           // beta holds the exact reciprocal
+    if (DIVMODE == 3) return __builtin_fmaf(num, beta, num * lo);      // beta holds hi
     return (float)((double)num * yd);
 }
 template <int DIVMODE>
-__device__ __forceinline__ v2f tb_div2(v2f num, float beta, double yd)
+__device__ __forceinline__ v2f tb_div2(v2f num, float beta, double yd, float lo = 0.f)
 {
     if constexpr (DIVMODE == 4) return num * beta;
-    else return (v2f){tb_div<DIVMODE>(num.x, beta, yd), tb_div<DIVMODE>(num.y, beta, yd)};
+    else if constexpr (DIVMODE == 3) {             // v_pk_mul_f32 + v_pk_fma_f32 (four plain v_mul / v_fmac: measured no better)
+        const v2f p = num * lo;
+        return __builtin_elementwise_fma(num, (v2f){beta, beta}, p);
+    } else return (v2f){tb_div<DIVMODE>(num.x, beta, yd), tb_div<DIVMODE>(num.y, beta, yd)};
 }
 
 // One lane's vector of one stage.  Its columns are worked on in pairs (0,1), (2,3), which is how every
@@ -517,7 +535,7 @@ __device__ __forceinline__ v2f tb_div2(v2f num, float beta, double yd)
 // Operand order and roundings are those of FluidSequential.c:93-94.
 template <int DIVMODE, int NV>
 __device__ __forceinline__ Vec<NV> tb_stencil(const Vec<NV>& up, const Vec<NV>& me, const Vec<NV>& dn, const Vec<NV>& r,
-                                              float alpha, float beta, double yd)
+                                              float alpha, float beta, double yd, float lo = 0.f)
 {
     float h[NV];
     h[0] = lane_below0(me.c[NV - 1]) + me.c[1];
@@ -532,7 +550,7 @@ __device__ __forceinline__ Vec<NV> tb_stencil(const Vec<NV>& up, const Vec<NV>& 
         s = s + (v2f){dn.c[p], dn.c[p + 1]};
         if constexpr (DIVMODE != 4) s = s * alpha;       // mode 4: alpha == 1.0f, x * 1.0f is x
         s = (v2f){r.c[p], r.c[p + 1]} + s;
-        s = tb_div2<DIVMODE>(s, beta, yd);
+        s = tb_div2<DIVMODE>(s, beta, yd, lo);
         G.c[p] = s.x;
         G.c[p + 1] = s.y;
     }
@@ -541,16 +559,24 @@ __device__ __forceinline__ Vec<NV> tb_stencil(const Vec<NV>& up, const Vec<NV>& 
 
 // All 2^32 float bit patterns a: does tb_div<DIVMODE>(a) equal a / beta bit for bit
 // (any NaN matches any NaN)?  Counts mismatches; the solver requires zero.
+// Mode 3 (arg = hi): its fallback, mode 2, must be exact for every a, and the two-term quotient for every a
+// that is zero or at least beta * 2^-98 in magnitude (the dividends the tile test lets through are zero or
+// at least beta * 2^-97, see DIVMODE 3).
 template <int DIVMODE>
-__global__ __launch_bounds__(256) void k_validate_div(float beta, float arg, double yd, unsigned long long* __restrict__ bad)
+__global__ __launch_bounds__(256) void k_validate_div(float beta, float arg, double yd, float lo, unsigned long long* __restrict__ bad)
 {
     unsigned long long n = 0;
     const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    auto differs = [](float got, float ref) { return (ref != ref) ? !(got != got) : (__float_as_uint(got) != __float_as_uint(ref)); };
     for (unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x; k < (1ull << 32); k += stride) {
         const float a = __uint_as_float((unsigned)k);
         const float ref = a / beta;
-        const float got = tb_div<DIVMODE>(a, arg, yd);
-        n += (ref != ref) ? !(got != got) : (__float_as_uint(got) != __float_as_uint(ref));
+        if constexpr (DIVMODE == 3) {
+            const bool in_range = a == 0.0f || !(__builtin_fabsf(a) < beta * 0x1p-98f);
+            n += differs(tb_div<2>(a, beta, yd), ref) || (in_range && differs(tb_div<3>(a, arg, yd, lo), ref));
+        } else {
+            n += differs(tb_div<DIVMODE>(a, arg, yd), ref);
+        }
     }
     if (n) atomicAdd(bad, n);
 }
@@ -677,7 +703,7 @@ __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[
 #pragma unroll
         for (int s = 1; s <= T; ++s) {
             const int q = t - s;                         // row this stage produces now (wave-uniform)
-            Vec<NV> G = tb_stencil<DIVMODE, NV>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.beta, a.yd);
+            Vec<NV> G = tb_stencil<DIVMODE, NV>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, DIVMODE == 3 ? a.hi : a.beta, a.yd, a.lo);
             float v1 = 0.f, vn = 0.f;
             if (EDGE) tb_fix_columns<S, NV>(G, a, v1, vn, WALL && s == T);
             if (s < T) W[s][FR] = G;
@@ -689,7 +715,7 @@ __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[
         for (int s = 1; s <= T; ++s) {
             const int q = t - s;
             const bool interior = (q >= 1 && q <= a.n);
-            Vec<NV> G = tb_stencil<DIVMODE, NV>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.beta, a.yd);
+            Vec<NV> G = tb_stencil<DIVMODE, NV>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, DIVMODE == 3 ? a.hi : a.beta, a.yd, a.lo);
             float v1 = 0.f, vn = 0.f;
             if (EDGE) tb_fix_columns<S, NV>(G, a, v1, vn, s == T);
             if (s < T) {
@@ -820,6 +846,8 @@ __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbB
     const int rbw = edge ? rb_edge : rb;
     TbArgs<S, NV> a;
     a.yd = yd;
+    a.lo = batch.lo[blockIdx.z];
+    a.hi = batch.hi[blockIdx.z];
     a.x0_inc = batch.x0_inc[blockIdx.z];
     a.q_lo = row_lo + strip * rbw;                       // this wave's output rows [q_lo, q_hi)
     if (a.q_lo >= row_hi) return;                        // wave-uniform
@@ -862,13 +890,69 @@ __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbB
     const int t0 = max(0, a.q_lo - T), t1 = a.q_hi - 1 + T;
     // a strip whose input rows [q_lo-T, q_hi-1+T] all exist never needs a regenerated ghost row
     const bool wall = (a.q_lo < T) || (a.q_hi - 1 + T > n + 1);      // wave-uniform
-    if (edge) {
-        if (wall) tb_march<T, DIVMODE, true, true, S, NV>(t0, t1, a);
-        else      tb_march<T, DIVMODE, true, false, S, NV>(t0, t1, a);
-    } else {
-        if (wall) tb_march<T, DIVMODE, false, true, S, NV>(t0, t1, a);
-        else      tb_march<T, DIVMODE, false, false, S, NV>(t0, t1, a);
+    constexpr int DM = DIVMODE == 3 ? 2 : DIVMODE;                   // what mode 3 falls back to
+    bool two_term = false;
+    if constexpr (DIVMODE == 3) {
+        // the two-term division if |x0| >= thr on every tile that this wave's part of the grid touches (DIVMODE 3
+        // above): the x0 rows q_lo-T+1 .. q_hi+T-2 are the ones that reach a cell this wave stores, the columns are
+        // those of its 64 * NV lanes; both clipped to the interior (ghost cells repeat interior values, and what
+        // lanes past the row's ends compute is never stored)
+        const unsigned* __restrict__ tiles = batch.tiles[blockIdx.z];
+        const unsigned thr = batch.tile_thr[blockIdx.z];
+        const int tr0 = (max(1, a.q_lo - T + 1) - 1) / kTileRows, tr1 = (min(n, a.q_hi + T - 2) - 1) / kTileRows;
+        const int c0 = max(1, 1 + NV * (win * VS - HL)), c1 = min(n, NV * (win * VS - HL + 64));
+        const int tc0 = (c0 - 1) / kTileCols, tc1 = (c1 - 1) / kTileCols, ntc = tc1 - tc0 + 1;
+        const int count = (tr1 - tr0 + 1) * ntc;
+        bool low = false;
+        if (tiles != nullptr)
+            for (int i = lane; i < count; i += 64)
+                low |= tiles[(size_t)(tr0 + i / ntc) * batch.tile_pitch + (tc0 + i % ntc)] < thr;
+        two_term = tiles != nullptr && __builtin_amdgcn_ballot_w64(low) == 0ull;
     }
+    if (two_term) {
+        if (edge) {
+            if (wall) tb_march<T, DIVMODE, true, true, S, NV>(t0, t1, a);
+            else      tb_march<T, DIVMODE, true, false, S, NV>(t0, t1, a);
+        } else {
+            if (wall) tb_march<T, DIVMODE, false, true, S, NV>(t0, t1, a);
+            else      tb_march<T, DIVMODE, false, false, S, NV>(t0, t1, a);
+        }
+    } else if (edge) {
+        if (wall) tb_march<T, DM, true, true, S, NV>(t0, t1, a);
+        else      tb_march<T, DM, true, false, S, NV>(t0, t1, a);
+    } else {
+        if (wall) tb_march<T, DM, false, true, S, NV>(t0, t1, a);
+        else      tb_march<T, DM, false, false, S, NV>(t0, t1, a);
+    }
+}
+
+// |x0| minima over tiles of kTileRows x kTileCols interior cells (tile (r, c): rows 1 + r*kTileRows ..., columns
+// 1 + c*kTileCols ...), as the bit pattern of a non-negative float (they order like unsigned integers), over the
+// rows [row_lo, row_hi) only.  One wave per 32 rows x 256 columns: 16 lanes x 4 columns make one tile.
+template <typename S>
+__global__ __launch_bounds__(256) void k_tile_min_abs(TileBatch tb, int pitch, int n, int row_lo, int row_hi, int tile_row0, int tile_pitch)
+{
+    const S* __restrict__ f = static_cast<const S*>(tb.field[blockIdx.z]);
+    unsigned* __restrict__ out = tb.tiles[blockIdx.z];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tr = tile_row0 + blockIdx.y;
+    const int j = 1 + 4 * (lane + 64 * (blockIdx.x * 4 + wave));         // first of this lane's four columns
+    const int i0 = max(row_lo, 1 + tr * kTileRows), i1 = min(row_hi, 1 + (tr + 1) * kTileRows);   // 1 <= row_lo, row_hi <= n+1
+    const size_t P = (size_t)pitch;
+    float m = __builtin_inff();
+    if (j <= n)
+        for (int i = i0; i < i1; ++i) {
+            const float4 v = ld4(f + (size_t)i * P + XOFF + j);           // columns past n read ghost / pad floats: masked below
+            m = fminf(m, fabsf(v.x));
+            if (j + 1 <= n) m = fminf(m, fabsf(v.y));
+            if (j + 2 <= n) m = fminf(m, fabsf(v.z));
+            if (j + 3 <= n) m = fminf(m, fabsf(v.w));
+        }
+    // fminf drops NaNs: a NaN in x0 makes every dividend it enters NaN, which any division mode returns as NaN
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 16));
+    // (the 16 lanes of a tile agree on i0 < i1; lane 0 of the group holds the tile's first column)
+    if ((lane & 15) == 0 && j <= n) out[(size_t)tr * tile_pitch + (j - 1) / kTileCols] = i0 < i1 ? __float_as_uint(m) : 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -1197,7 +1281,8 @@ void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void
 }
 
 // T in {8,4,2} sweeps per launch, nv in {2,4} columns per lane; batch.count solves per launch.
-// divmode 0: beta; 2: beta unused, yd = RN64(1/beta); 4: beta = exact reciprocal of a power of two and alpha == 1.
+// divmode 0: beta; 2: beta unused, yd = RN64(1/beta); 4: beta = exact reciprocal of a power of two and alpha == 1;
+// 3: hi, lo = the two-term reciprocal where the tiles of |x0| minima allow it, yd elsewhere.
 void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const TbBatch& batch, int pitch, int n, int row_lo,
                       int row_hi, int rb, int rb_edge)
 {
@@ -1226,10 +1311,12 @@ void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const T
     else FLUID_TB2(TT, DD, 4)
 #define FLUID_TB(TT)                          \
     if (divmode == 4) { FLUID_TB1(TT, 4); }      \
+    else if (divmode == 3) { FLUID_TB1(TT, 3); } \
     else if (divmode == 2) { FLUID_TB1(TT, 2); } \
     else { FLUID_TB1(TT, 0); }
     if (T == 16) {                                       // 2-column lanes only (4-column ones would need > 256 registers)
         if (divmode == 4) { FLUID_TB2(16, 4, 2); }
+        else if (divmode == 3) { FLUID_TB2(16, 3, 2); }
         else if (divmode == 2) { FLUID_TB2(16, 2, 2); }
         else { FLUID_TB2(16, 0, 2); }
     }
@@ -1241,11 +1328,23 @@ void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const T
 #undef FLUID_TB2
 }
 
-// mismatches of division mode `divmode` against a/beta over all 2^32 inputs are added to *bad
-void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, double yd, unsigned long long* bad)
+// tiles of |x0| minima for division mode 3, rows [row_lo, row_hi) within 1..n+1; tb.tiles[k] holds tile_rows(n) x tile_pitch words
+void launch_tile_min_abs(hipStream_t s, int st, const TileBatch& tb, int count, int pitch, int n, int row_lo, int row_hi, int tile_pitch)
 {
-    if (divmode == 4) hipLaunchKernelGGL((k_validate_div<4>), dim3(8192), dim3(256), 0, s, beta, arg, yd, bad);
-    else hipLaunchKernelGGL((k_validate_div<2>), dim3(8192), dim3(256), 0, s, beta, arg, yd, bad);
+    if (row_lo < 1) row_lo = 1;
+    if (row_hi > n + 1) row_hi = n + 1;
+    if (row_hi <= row_lo || count <= 0) return;
+    const int tr0 = (row_lo - 1) / kTileRows, tr1 = (row_hi - 2) / kTileRows;
+    const dim3 grid(cdiv(cdiv(n, 4), 256), tr1 - tr0 + 1, count);
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_tile_min_abs<S>, grid, dim3(256), 0, s, tb, pitch, n, row_lo, row_hi, tr0, tile_pitch));
+}
+
+// mismatches of division mode `divmode` against a/beta over all 2^32 inputs are added to *bad
+void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, double yd, float lo, unsigned long long* bad)
+{
+    if (divmode == 4) hipLaunchKernelGGL((k_validate_div<4>), dim3(8192), dim3(256), 0, s, beta, arg, yd, lo, bad);
+    else if (divmode == 3) hipLaunchKernelGGL((k_validate_div<3>), dim3(8192), dim3(256), 0, s, beta, arg, yd, lo, bad);
+    else hipLaunchKernelGGL((k_validate_div<2>), dim3(8192), dim3(256), 0, s, beta, arg, yd, lo, bad);
 }
 
 void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u, const void* v, int pitch, int n,

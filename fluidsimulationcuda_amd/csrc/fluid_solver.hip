@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -65,6 +66,7 @@ struct fluid_ctx {
     void* f[FLUID_NFIELDS] = {};
     size_t field_bytes = 0;
     unsigned int* d_scalar = nullptr;     // device word for the reductions
+    unsigned int* tiles = nullptr;        // 3 x tile_rows x tile_pitch words: |x0| minima per tile for division mode 3
     unsigned int* h_scalar = nullptr;     // pinned host mirror
     hipEvent_t scalar_ready = nullptr;    // recorded behind the scalar's device-to-host copy
     int variant = fluid::JACOBI_TB;
@@ -76,8 +78,8 @@ struct fluid_ctx {
     bool in_halo_exchange = false;
     int tb_nv = 2;                                 // columns per lane of the fused kernel (2: 4 waves/SIMD; 4: 2 waves/SIMD)
     int tb_edge_pct = 40;                          // strip height of the two edge windows, % of the others'
-    bool fast_div = true;                          // allow division modes 1/2/4 (each beta proven on the device first)
-    std::unordered_map<unsigned long long, int> div_mode;   // (wanted mode, beta bits) -> proven division mode
+    int fast_div = 1;                              // 0: always divide; 1: division modes 2/3/4 allowed (each beta proven on the
+                                                   // device first); 2: as 1 without the guarded two-term mode 3
     // slab decomposition
     int rank = 0, nranks = 1, own0 = 1, own1 = 1, min_slab = 0, halo = 1;
     int reach[FLUID_NFIELDS] = {};            // see "row-slab bookkeeping" below
@@ -200,43 +202,88 @@ int timing_collect(fluid_ctx* c)
         TRY(timing_end((c), stop_, 0));          \
     } while (0)
 
-// Division mode for `beta` in the temporally blocked kernel: 0 = true division,
-// 4 = multiply by the exact reciprocal (beta a power of two, alpha 1), 2 = f64 reciprocal
-// multiply.  Modes 2 and 4 are only used after k_validate_div has compared them
-// with a/beta for every one of the 2^32 float inputs on this device (a few ms,
-// once per beta and context).
-int division_mode(fluid_ctx* c, float beta, float alpha, float* arg, double* yd)
+// Division mode for `beta` in the temporally blocked kernel (fluid_kernels.hip, DIVMODE): 0 = true division,
+// 4 = multiply by the exact reciprocal (beta a power of two, alpha 1), 3 = guarded two-term reciprocal
+// (hi, lo; two packed instructions per pair of cells), 2 = f64 reciprocal multiply.  Modes 2, 3 and 4 are only
+// used after k_validate_div has proven them against a/beta for every one of the 2^32 float inputs on this
+// device -- a few ms, once per (mode, beta) and PROCESS: the proof is about the arithmetic of the device
+// type, so contexts share it (a fresh context used to spend 3 x 2.5 ms re-proving the step's three betas).
+struct DivProofs {
+    std::mutex mu;
+    std::unordered_map<unsigned long long, int> proven;     // (device, wanted mode, beta bits) -> mode to use
+};
+DivProofs& div_proofs()
 {
-    *arg = beta;
-    *yd = 1.0 / (double)beta;
-    if (!c->fast_div || !(beta > 0.f) || !std::isfinite(beta)) return 0;
+    static DivProofs p;
+    return p;
+}
+
+struct DivPlan {
+    int mode = 0;
+    float arg = 0.f;      // what the kernel receives as `beta`: beta (0, 2, 3), 1/beta (4)
+    float hi = 0.f, lo = 0.f;   // mode 3: the two-term reciprocal
+    unsigned tile_thr = 0;      // mode 3: bits of beta * 2^-72, what |x0| must reach on a tile (fluid_kernels.hip, DIVMODE 3)
+    double yd = 0.0;      // modes 2, 3
+};
+
+float round_down_to_float(double v)
+{
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+
+DivPlan division_mode(fluid_ctx* c, float beta, float alpha)
+{
+    DivPlan plan;
+    plan.arg = beta;
+    plan.yd = 1.0 / (double)beta;
+    if (c->fast_div == 0 || !(beta > 0.f) || !std::isfinite(beta)) return plan;
     int e2 = 0;
     const float rbeta = 1.0f / beta;
     const bool pow2 = std::frexp(beta, &e2) == 0.5f && std::isnormal(rbeta) && rbeta * beta == 1.0f;
+    const float hi = round_down_to_float(plan.yd), lo = (float)(plan.yd - (double)hi);
     // mode 4 (pressure solve: alpha 1, beta 4): multiply by the exact reciprocal, and x * 1.0f is x so
-    // alpha is not applied at all; anything else: mode 2, the double-precision reciprocal
-    const int want = (pow2 && alpha == 1.0f) ? 4 : 2;
+    // alpha is not applied at all; else mode 3 when 1/beta splits into two normal floats with lo > 0
+    // (not for powers of two: lo = 0 turns inf * lo into NaN); else mode 2, the double-precision reciprocal.
+    // A mode that fails its proof hands over to the next: 3 -> 2 -> 0, 4 -> 2 -> 0.
+    const bool two_term = c->fast_div == 1 && c->tiles && beta >= 1.0f && beta <= 0x1p24f && std::isnormal(hi) && std::isnormal(lo) && lo > 0.f;
+    int want = (pow2 && alpha == 1.0f) ? 4 : two_term ? 3 : 2;
     unsigned bits;
     std::memcpy(&bits, &beta, sizeof bits);
-    const unsigned long long key = ((unsigned long long)want << 32) | bits;
-    auto it = c->div_mode.find(key);
-    int mode;
-    if (it != c->div_mode.end()) {
-        mode = it->second;
-    } else {
-        mode = want;
-        unsigned long long* bad = reinterpret_cast<unsigned long long*>(c->d_scalar) + 1;   // 8-byte slot of the 256-B block
-        unsigned long long* hbad = reinterpret_cast<unsigned long long*>(c->h_scalar) + 1;
-        if (hipMemsetAsync(bad, 0, sizeof *bad, c->stream) != hipSuccess) return 0;
-        fluid::launch_validate_div(c->stream, mode, beta, mode == 4 ? rbeta : beta, *yd, bad);
-        if (hipMemcpyAsync(hbad, bad, sizeof *bad, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess)
-            return 0;
-        if (*hbad != 0) mode = 0;                  // never observed; keeps the bit-exact contract regardless
-        c->div_mode.emplace(key, mode);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    DivProofs& proofs = div_proofs();
+    std::lock_guard<std::mutex> lock(proofs.mu);
+    int mode = 0;
+    while (want != 0) {
+        const unsigned long long key = ((unsigned long long)(dev & 0xFF) << 40) | ((unsigned long long)want << 32) | bits;
+        auto it = proofs.proven.find(key);
+        if (it != proofs.proven.end()) {
+            mode = it->second;
+        } else {
+            unsigned long long* bad = reinterpret_cast<unsigned long long*>(c->d_scalar) + 1;   // 8-byte slot of the 256-B block
+            unsigned long long* hbad = reinterpret_cast<unsigned long long*>(c->h_scalar) + 1;
+            if (hipMemsetAsync(bad, 0, sizeof *bad, c->stream) != hipSuccess) return plan;
+            fluid::launch_validate_div(c->stream, want, beta, want == 4 ? rbeta : want == 3 ? hi : beta, plan.yd, lo, bad);
+            if (hipMemcpyAsync(hbad, bad, sizeof *bad, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess)
+                return plan;
+            mode = *hbad == 0 ? want : 0;
+            proofs.proven.emplace(key, mode);
+        }
+        if (mode != 0) break;
+        want = want == 2 ? 0 : 2;
     }
-    if (mode == 4) *arg = rbeta;
-    return mode;
+    plan.mode = mode;
+    if (mode == 4) plan.arg = rbeta;
+    if (mode == 3) {
+        plan.hi = hi;
+        plan.lo = lo;
+        const float thr = beta * 0x1p-72f;
+        std::memcpy(&plan.tile_thr, &thr, sizeof thr);
+    }
+    return plan;
 }
 
 // ---- row-slab bookkeeping ------------------------------------------------------
@@ -426,17 +473,36 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
     TRY(timing_begin(c, FLUID_TIME_DIFFUSION, &stop));
     const bool multi = c->nranks > 1;
     int cur[3], nxt[3], divmode[3];
-    float div_arg[3];
-    double yd[3];
+    DivPlan plan[3];
     bool same_mode = true, all_mode4 = true;
     for (int k = 0; k < count; ++k) {
         cur[k] = sv[k].x;
         nxt[k] = kScratch[k];
-        div_arg[k] = sv[k].beta;
-        yd[k] = 0.0;
-        divmode[k] = c->variant == fluid::JACOBI_TB ? division_mode(c, sv[k].beta, sv[k].alpha, &div_arg[k], &yd[k]) : 0;
+        plan[k].arg = sv[k].beta;
+        if (c->variant == fluid::JACOBI_TB) plan[k] = division_mode(c, sv[k].beta, sv[k].alpha);
+        divmode[k] = plan[k].mode;
         same_mode = same_mode && divmode[k] == divmode[0];
         all_mode4 = all_mode4 && divmode[k] == 4;
+    }
+    // division mode 3 needs |x0| >= beta * 2^-72 wherever it is used: minima of |x0| per tile, once per solve (x0 does not
+    // change during it), over the rows of x0 that are valid here; tiles beyond them read 0 = "divide the long way"
+    const size_t tile_words = (size_t)fluid::tile_rows(c->n) * fluid::tile_pitch(c->n);
+    {
+        fluid::TileBatch tb{};
+        int m = 0, valid = kEverywhere;
+        for (int k = 0; k < count; ++k)
+            if (divmode[k] == 3) {
+                tb.field[m] = c->f[sv[k].x0];
+                tb.tiles[m] = c->tiles + (size_t)k * tile_words;
+                valid = std::min(valid, c->nranks > 1 ? c->reach[sv[k].x0] : kEverywhere);
+                ++m;
+            }
+        if (m > 0) {
+            if (c->nranks > 1) HIP_TRY(hipMemsetAsync(c->tiles, 0, 3 * tile_words * sizeof(unsigned), c->stream));
+            int lo, hi;
+            rows(c, std::min(valid, c->n), &lo, &hi);
+            fluid::launch_tile_min_abs(c->stream, c->st, tb, m, c->pitch, c->n, lo, hi, fluid::tile_pitch(c->n));
+        }
     }
     auto reach_now = [&]() {
         int r = kEverywhere;
@@ -496,14 +562,19 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                     bt.x0[m] = c->f[sv[j].x0];
                     bt.out[m] = c->f[nxt[j]];
                     bt.alpha[m] = sv[j].alpha;
-                    bt.beta[m] = div_arg[j];
-                    bt.yd[m] = yd[j];
+                    bt.beta[m] = plan[j].arg;
+                    bt.yd[m] = plan[j].yd;
+                    bt.hi[m] = plan[j].hi;
+                    bt.lo[m] = plan[j].lo;
+                    bt.tiles[m] = divmode[j] == 3 ? c->tiles + (size_t)j * tile_words : nullptr;
+                    bt.tile_thr[m] = plan[j].tile_thr;
                     bt.b[m] = sv[j].b;
                     bt.x_zero[m] = c->zero[cur[j]] ? 1 : 0;
                     bt.x0_inc[m] = c->pend[sv[j].x0] ? c->pend_inc[sv[j].x0] : -0.0f;     // x + (-0) is x for every x
                     ++m;
                 }
                 bt.count = m;
+                bt.tile_pitch = fluid::tile_pitch(c->n);
                 int rb = c->tb_rows;
                 const int edge_pct = c->tb_edge_pct > 0 ? c->tb_edge_pct : 100;
                 auto edge_rows = [&](int r) { return std::max(2 * T, r * edge_pct / 100); };
@@ -986,6 +1057,11 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
     }
     if (!hip_ok(hipMemsetAsync(c->arena, 0, bytes, c->stream), "hipMemsetAsync(arena)")) return bail(rc);
     c->d_scalar = reinterpret_cast<unsigned int*>(c->arena + c->field_bytes * FLUID_NFIELDS);   // RCCL-addressable
+    {
+        const size_t words = 3 * (size_t)fluid::tile_rows(n) * fluid::tile_pitch(n);
+        if (!hip_ok(hipMalloc((void**)&c->tiles, words * sizeof(unsigned)), "hipMalloc(tiles)")) return bail(rc);
+        if (!hip_ok(hipMemsetAsync(c->tiles, 0, words * sizeof(unsigned), c->stream), "hipMemsetAsync(tiles)")) return bail(rc);
+    }
     if (!hip_ok(hipHostMalloc((void**)&c->h_scalar, 256, hipHostMallocDefault), "hipHostMalloc")) return bail(rc);
     if (!hip_ok(hipEventCreateWithFlags(&c->scalar_ready, hipEventDisableTiming), "hipEventCreate")) return bail(rc);
     if (!hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return bail(rc);
@@ -1012,6 +1088,7 @@ int fluid_destroy(fluid_ctx* c)
         (void)hipEventDestroy(p.b);
     }
     if (c->h_scalar) (void)hipHostFree(c->h_scalar);
+    if (c->tiles) (void)hipFree(c->tiles);
     if (c->scalar_ready) (void)hipEventDestroy(c->scalar_ready);
     if (c->own_arena && c->arena) (void)hipFree(c->arena);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1127,7 +1204,8 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
         c->tb_min_cells = value;
         return FLUID_OK;
     case FLUID_PARAM_TB_FAST_DIVISION:
-        c->fast_div = value != 0;
+        if (value < 0 || value > 2) return fail(FLUID_E_INVALID, "TB_FAST_DIVISION must be 0, 1 or 2");
+        c->fast_div = value;
         return FLUID_OK;
     case FLUID_PARAM_TB_T16_MIN_CELLS:
         if (value < -1) return fail(FLUID_E_INVALID, "TB_T16_MIN_CELLS must be >= 0, or -1 for the default rule");
@@ -1144,6 +1222,14 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
     default:
         return fail(FLUID_E_INVALID, "unknown parameter %d", key);
     }
+}
+
+int fluid_division_mode(fluid_ctx* c, float alpha, float beta, int* mode)
+{
+    TRY(check_ctx(c));
+    if (!mode) return fail(FLUID_E_INVALID, "null pointer");
+    *mode = c->variant == fluid::JACOBI_TB ? division_mode(c, beta, alpha).mode : 0;
+    return FLUID_OK;
 }
 
 int fluid_set_exchange(fluid_ctx* c, fluid_exchange_fn fn, void* user)

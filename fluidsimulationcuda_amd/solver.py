@@ -150,6 +150,12 @@ class FluidSolver:
     def set_jacobi_variant(self, variant):
         capi.check(capi.lib().fluid_set_jacobi_variant(self._h, variant))
 
+    def division_mode(self, alpha, beta):
+        """0 true division, 2 double reciprocal, 3 two-term reciprocal (tile-proved), 4 exact reciprocal."""
+        m = C.c_int()
+        capi.check(capi.lib().fluid_division_mode(self._h, alpha, beta, C.byref(m)))
+        return m.value
+
     def set_param(self, key, value):
         capi.check(capi.lib().fluid_set_param(self._h, key, value))
 

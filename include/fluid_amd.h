@@ -56,9 +56,11 @@ enum {
     FLUID_PARAM_TB_ROWS = 1,       /* output rows per wave strip of FLUID_JACOBI_TB; 0 = auto          */
     FLUID_PARAM_HALO = 2,          /* multi-GPU ghost-zone depth (clamped to slab height - 1)          */
     FLUID_PARAM_TB_FAST_DIVISION = 3 /* 1 (default): FLUID_JACOBI_TB may replace x/beta by an exactly equivalent
-                                      reciprocal multiply (in double; in float when beta is a power of two),
-                                      after proving the equivalence for that beta on all 2^32 float inputs
-                                      on the device; 0: always divide                                    */
+                                      reciprocal form -- one float multiply when beta is a power of two, else a
+                                      guarded two-term float reciprocal (fma(x, hi, x*lo), quotients in
+                                      (0, 2^-100) redone in double), else a double multiply -- each after proving
+                                      the equivalence for that beta on all 2^32 float inputs on the device;
+                                      2: the same without the two-term form; 0: always divide            */
     ,FLUID_PARAM_TB_EDGE_ROWS_PCT = 5 /* strip height of the two windows that carry the ghost columns, in % of
                                       the interior windows' (default 40; 0 = same): load balance only  */
     ,FLUID_PARAM_TB_LANE_COLUMNS = 6 /* columns per lane of FLUID_JACOBI_TB: 2 (default; thin waves, 4 per SIMD)
@@ -170,6 +172,10 @@ int fluid_residual(fluid_ctx *ctx, int x, int x0, float alpha, float beta, float
 int fluid_absmax_velocity(fluid_ctx *ctx, int u, int v, float *out);
 
 int fluid_set_jacobi_variant(fluid_ctx *ctx, int variant);
+/* How FLUID_JACOBI_TB divides by `beta` in a solve with these coefficients (diagnostic; runs the on-device proof
+ * if this beta has not been seen): 0 true division, 2 double-precision reciprocal, 3 two-term float reciprocal
+ * where the right-hand side allows it (else as 2), 4 exact float reciprocal (beta a power of two, alpha 1). */
+int fluid_division_mode(fluid_ctx *ctx, float alpha, float beta, int *mode);
 int fluid_set_param(fluid_ctx *ctx, int key, int value);
 
 /* ---- timing: HIP events on the context's stream around every operator -------

@@ -290,7 +290,7 @@ def test_temporal_blocking_reciprocal_division_is_exact(F, oracle, beta):
                         dtype=np.float32)
     with F.FluidSolver(n, jacobi=capi.JACOBI_TB) as s:
         s.set_param(capi.PARAM_TB_MIN_CELLS, 0)
-        for fast in (1, 0):
+        for fast in (1, 2, 0):       # guarded two-term reciprocal / double reciprocal / true division
             s.set_param(capi.PARAM_TB_FAST_DIVISION, fast)
             for kind in ("uniform", "special", "tiny"):
                 if kind == "uniform":
@@ -312,6 +312,76 @@ def test_temporal_blocking_reciprocal_division_is_exact(F, oracle, beta):
                     assert np.array_equal(np.isnan(got), nan)
                     assert_bit_equal(np.where(nan, 0, got), np.where(nan, 0, want),
                                      "beta=%g fast=%d %s alpha=%g" % (beta, fast, kind, alpha))
+
+
+@pytest.mark.parametrize("max_t", [16, 8, 2])
+@pytest.mark.parametrize("n", [97, 300, 1022])
+def test_two_term_division_only_where_the_right_hand_side_allows_it(F, oracle, n, max_t):
+    """Division mode 3 (two packed float instructions) is exact for dividends that are zero or at least
+    beta * 2^-98; the kernel uses it in a wave only if |x0| >= beta * 2^-72 on every tile the wave touches,
+    which bounds every dividend of every sweep from below (fluid_kernels.hip, DIVMODE 3).  Ordinary values
+    with islands of exact zeros (both signs), of tiny values (2^-149 .. 2^-60) and of huge ones, in x0 and in
+    the first guess: every cell must still carry the oracle's bits."""
+    from fluidsimulationcuda_amd import capi
+    rng = np.random.default_rng(n + max_t)
+    alpha, beta = F.coefficients(n, DT, VISC)
+
+    def field(islands):
+        f = rnd(rng, n)
+        for _ in range(islands):
+            i, j = rng.integers(1, n, 2)
+            h, w = rng.integers(1, 40, 2)
+            kind = rng.integers(0, 4)
+            blk = f[i:i + h, j:j + w]
+            if kind == 0:
+                blk[...] = np.where(rng.random(blk.shape) < 0.5, 0.0, -0.0)
+            elif kind == 1:
+                blk[...] = (blk * np.float32(2.0) ** rng.integers(-149, -60, blk.shape)).astype(np.float32)
+            elif kind == 2:
+                blk[...] = blk * np.float32(1e-37)
+            else:
+                blk[...] = blk * np.float32(1e37)
+        return f
+
+    with F.FluidSolver(n, params={capi.PARAM_TB_MIN_CELLS: 0, capi.PARAM_TB_T16_MIN_CELLS: 0,
+                                  capi.PARAM_TB_MAX_SWEEPS: max_t}) as s:
+        assert s.division_mode(alpha, beta) == 3 and s.division_mode(1.0, 4.0) == 4
+        for b, islands in ((0, 6), (1, 0), (2, 2)):
+            x, x0 = field(6), field(islands)
+            s.upload(u=x, v=x0)
+            s.diffuse(b, "u", "v", alpha, beta, 16)
+            want = x.copy()
+            with np.errstate(all="ignore"):
+                oracle.diffuse(b, want, x0, alpha, beta, 16)
+            got, nan = s.download("u"), np.isnan(want)       # inf - inf next to the huge islands: any NaN is a NaN
+            assert np.array_equal(np.isnan(got), nan)
+            assert_bit_equal(np.where(nan, 0, got), np.where(nan, 0, want), "two-term division n=%d maxT=%d b=%d" % (n, max_t, b))
+
+
+@pytest.mark.parametrize("n", [300, 1022])
+def test_two_term_division_worst_case_cancellation(F, oracle, n):
+    """The lower bound on the dividends is what makes mode 3 safe without a per-value check: x0 >= m does not keep
+    x0 + alpha*nb away from zero, only away from (0, 2^-25 m).  First guesses built to cancel the right-hand
+    side as closely as floats allow (x = -x0 / (4 alpha) and neighbours of it one ulp apart) drive the dividends
+    of the first sweeps to their smallest possible nonzero magnitudes; x0 itself sits just above the tile
+    threshold beta * 2^-72."""
+    from fluidsimulationcuda_amd import capi
+    rng = np.random.default_rng(n)
+    alpha, beta = F.coefficients(n, DT, VISC)
+    for scale in (np.float32(beta) * np.float32(2.0 ** -71), np.float32(1.0)):
+        x0 = (rnd(rng, n, 1.0, 2.0) * scale * rng.choice(np.array([-1, 1], np.float32), (n + 2, n + 2))).astype(np.float32)
+        x = (-x0 / (np.float32(4) * np.float32(alpha))).astype(np.float32)
+        x = np.nextafter(x, np.float32(np.inf) * rng.choice(np.array([-1, 1], np.float32), x.shape)).astype(np.float32)
+        # smooth x0 so that the four neighbours of a cell cancel it too
+        x0[...] = x0[n // 2, n // 2]
+        x[...] = np.where(rng.random(x.shape) < 0.5, x[n // 2, n // 2], np.nextafter(x[n // 2, n // 2], np.float32(0)))
+        with F.FluidSolver(n, params={capi.PARAM_TB_MIN_CELLS: 0}) as s:
+            assert s.division_mode(alpha, beta) == 3
+            s.upload(u=x, v=x0)
+            s.diffuse(0, "u", "v", alpha, beta, 8)
+            want = x.copy()
+            oracle.diffuse(0, want, x0, alpha, beta, 8)
+            assert_bit_equal(s.download("u"), want, "cancellation, scale %g" % scale)
 
 
 def test_exact_cancellations_and_signed_zeros(F, oracle):
