@@ -17,6 +17,13 @@ Workload: N=1 -> 4096^2 (the grid BASELINE.json's metric is quoted on, config
 2); N>1 -> 8192^2 split into row slabs (config 3), strong scaling.  The N=1
 line also carries the 1-GPU 8192^2 measurement ("scaling_base") so the 8192^2
 speed-up can be formed from the driver's own runs.
+
+Two data regimes are reported.  The headline follows the reference's loop: sources only at step 0, zeroed
+afterwards (FluidSequential.c:298-302), so every solve restarts from a zero first guess and the fields decay
+by 1-2 orders of magnitude per step -- the timed steps run on small, then tiny values.  `value_ordinary_data`
+repeats the measurement with the synthetic sources re-injected before every step (device-to-device copies,
+timed apart), i.e. on fields of ordinary magnitude: the chip holds a lower clock on such data and the
+diffusion solves can use their cheaper exact division there.
 """
 import argparse
 import json
@@ -31,6 +38,10 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 KERNELS = ["stream", "lds", "naive", "tb"]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+# what one SIMD sustains of the fused kernel's instruction mix (packed f32, DPP adds, f64 / conversions: 4 cycles
+# each), in wave-instructions per microsecond with >= 4 waves resident: tools/ubench/valu_peak.hip on MI355X
+VALU_PEAK_PER_SIMD_US = 570.0
+SIMDS = 1024
 BYTES_PER_CELL_SWEEP = 12      # read x + read x0 + write x_new, fp32 (6 with fp16 storage)
 BYTES_PER_CELL_STEP = 2548     # SURVEY.md 8(d), 40 sweeps/solve
 
@@ -45,77 +56,119 @@ def parse():
     ap.add_argument("--variant", type=int, default=3, help="Jacobi kernel: 0 stream, 1 LDS-tiled, 2 naive, 3 temporally blocked")
     ap.add_argument("--tb-sweeps", type=int, default=0, help="temporal blocking: most sweeps per launch (16, 8, 4, 2; 0 = default)")
     ap.add_argument("--tb-rows", type=int, default=0, help="temporal blocking: rows per wave strip (0 = auto)")
+    ap.add_argument("--fast-division", type=int, default=-1, help="FLUID_PARAM_TB_FAST_DIVISION (default: library's)")
     ap.add_argument("--halo", type=int, default=0, help="multi-GPU ghost-zone depth (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scaling-base", action="store_true")
+    ap.add_argument("--no-ordinary", action="store_true", help="skip the value_ordinary_data leg")
+    ap.add_argument("--only-ordinary", action="store_true", help="profiling aid: run only the ordinary-data leg")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="field storage: f32 (reference arithmetic, the measured configuration) or f16 "
                          "(BASELINE config 4: fp16 fields, fp32 arithmetic)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured path) or gloo (host-staged rehearsal "
                                                       "of the multi-process path when ranks outnumber GPUs)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "torch"],
+                    help="multi-GPU halo exchange: the library's own RCCL exchange (C++, no host wait) or "
+                         "torch.distributed (auto: rccl with --backend nccl)")
     ap.add_argument("--check", action="store_true", help="multi-GPU: also verify bit equality with a 1-context run (small grids)")
     return ap.parse_args()
 
 
-def measure(solver, dist, world, steps, warmup, iters, cells):
-    """W untimed steps, then exactly K timed steps between barrier+synchronize
-    pairs; returns (max-over-ranks seconds, max-over-ranks Jacobi ms, sweeps, Jacobi launches,
-    launches counted once per field swept, max-over-ranks ms in the pressure solves, their sweeps)."""
+def timed_steps(solver, dist, world, steps, iters, before_step=None):
+    """Exactly `steps` steps between barrier+synchronize pairs; returns the max-over-ranks seconds, Jacobi ms,
+    pressure-solve ms and the timing record."""
     import torch
-    solver.step(1, use_sources=True, iters=iters)          # z == 0 consumes the synthetic sources
-    for _ in range(max(warmup - 1, 0)):
-        solver.step(1, iters=iters)
     solver.timing_enable(True)
     solver.timing_read(reset=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    solver.step(steps, iters=iters)
+    if before_step is None:
+        solver.step(steps, iters=iters)
+    else:
+        for _ in range(steps):
+            before_step()
+            solver.step(1, use_sources=True, iters=iters)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     t = solver.timing_read(reset=True)
     solver.timing_enable(False)
-    jac_ms, sweeps, prs_ms = t["jacobi_ms"], t["sweeps"], t["pressure_ms"]
+    jac_ms, prs_ms = t["jacobi_ms"], t["pressure_ms"]
     if world > 1:
         buf = torch.tensor([elapsed, jac_ms, prs_ms], dtype=torch.float64,
                            device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(buf, op=dist.ReduceOp.MAX)
         elapsed, jac_ms, prs_ms = float(buf[0]), float(buf[1]), float(buf[2])
-    return elapsed, jac_ms, sweeps, t["jacobi_launches"], t["jacobi_field_launches"], prs_ms, t["pressure_sweeps"]
+    return elapsed, jac_ms, prs_ms, t
 
 
-def pmc_traffic(kernel, grid):
-    """Mean HBM bytes per launch of the dominant kernel (all its instantiations, weighted by how often
-    each ran) from the committed rocprofv3 PMC summary (profiles/r*_<grid>_pmc.json, written by
-    tools/summarize_profiles.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this same
-    command, gfx950 x2 read correction applied).  The newest summary wins; None when none matches."""
+def measure(solver, dist, world, steps, warmup, iters):
+    """The reference's loop: sources at step 0 only.  W untimed steps, then exactly K timed ones."""
+    solver.step(1, use_sources=True, iters=iters)          # z == 0 consumes the synthetic sources
+    for _ in range(max(warmup - 1, 0)):
+        solver.step(1, iters=iters)
+    return timed_steps(solver, dist, world, steps, iters)
+
+
+def measure_ordinary(solver, fields, steps, warmup, iters):
+    """Sources re-injected before every step (one GPU): device copies of the three source fields are written into
+    u_prev / v_prev / dens_prev, then one step consumes them.  Returns timed_steps()'s tuple plus the time the
+    copies alone take per step."""
+    import torch
+    src = {k: torch.from_numpy(fields[k]).to(solver.device) for k in ("u_prev", "v_prev", "dens_prev")}
+
+    def inject():
+        with torch.cuda.stream(solver.torch_stream):
+            for k, t in src.items():
+                solver.interior(k).copy_(t, non_blocking=True)
+
+    for _ in range(max(warmup, 1)):
+        inject()
+        solver.step(1, use_sources=True, iters=iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        inject()
+    torch.cuda.synchronize()
+    copy_ms = (time.perf_counter() - t0) * 1e3 / steps
+    return timed_steps(solver, None, 1, steps, iters, before_step=inject) + (copy_ms,)
+
+
+def pmc_summary(grid):
+    """The newest committed rocprofv3 PMC summary of this bench command at this grid
+    (profiles/r*_<grid>_pmc.json, tools/profile_bench.sh + tools/summarize_profiles.py): separate
+    --pmc passes for FETCH_SIZE, WRITE_SIZE (gfx950 corrections applied) and SQ_INSTS_VALU."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%d_pmc.json" % grid))):
         try:
-            d = json.load(open(f))
+            best = (json.load(open(f)), os.path.basename(f))
         except (OSError, ValueError):
             continue
-        tot = cnt = 0.0
-        for name, v in d.items():
-            if name.split("<")[0] != kernel or not v.get("hbm_bytes_per_launch"):
-                continue
-            tot += v["hbm_bytes_per_launch"] * v["launches_sampled"]
-            cnt += v["launches_sampled"]
-        if cnt:
-            best = (tot / cnt, os.path.basename(f))
     return best
+
+
+def pmc_per_launch(summary, kernel, key):
+    """Mean of `key` per launch over all instantiations of `kernel`, weighted by how often each ran."""
+    tot = cnt = 0.0
+    for name, v in summary.items():
+        if name.split("<")[0] != kernel or not v.get(key):
+            continue
+        tot += v[key] * v["launches_sampled"]
+        cnt += v["launches_sampled"]
+    return tot / cnt if cnt else None
 
 
 def cpu_baseline(n, fields, iters):
     """The oracle leg (checker only): one full step and one 40-sweep pressure
     solve on ONE host core at the bench workload's N -- the reference itself
-    (oracle/_ref, kind "reference") when its build for this N travelled here,
-    else the restatement (kind "port")."""
+    (oracle/_ref, kind "reference") when its build for this N travelled here
+    (it is git-ignored: a fresh clone reports the restatement, kind "port").  Plus the restatement's
+    solve on all host cores (POSIX threads over row bands, oracle/fluid_oracle.c: fo_diffuse_mt)."""
     import numpy as np
     from oracle.oracle import Oracle, Reference, have_ref
     f = {k: v.copy() for k, v in fields.items()}
@@ -138,17 +191,21 @@ def cpu_baseline(n, fields, iters):
     out = {"value": w * w / (t_solve / iters) / 1e6, "unit": "Mcells/s per Jacobi iter", "cores": 1,
            "kind": "reference" if use_ref else "port", "ms_per_step": t_step * 1e3,
            "sample": "1 full step (200 sweeps) + one %d-sweep pressure solve at %dx%d, gcc -O2, 1 thread"
-                     % (iters, w, w)}
-    # secondary line: the restatement's sweep split into row bands over all host cores
+                     % (iters, w, w),
+           "note": "kind 'reference' = project/sequential itself from oracle/_ref (built in the dev container, "
+                   "git-ignored, shipped with the snapshot); without it the bit-identical restatement runs (kind 'port')"}
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, 16)          # one GPU's share of the host; more Python threads only add hand-off cost
     if cores > 1:
+        threads = min(cores, 64)
         p2 = np.zeros((w, w), np.float32)
+        Oracle().diffuse_threaded(0, p2, div, 1.0, 4.0, 2, threads)          # spin the threads up once
+        sweeps = 16
         t0 = time.perf_counter()
-        Oracle().diffuse_threaded(0, p2, div, 1.0, 4.0, 8, cores)
-        t_mt = (time.perf_counter() - t0) / 8
-        out["all_cores"] = {"value": w * w / t_mt / 1e6, "unit": "Mcells/s per Jacobi iter", "cores": cores,
-                            "kind": "port", "sample": "8 sweeps of the pressure solve, row bands over %d threads" % cores}
+        Oracle().diffuse_threaded(0, p2, div, 1.0, 4.0, sweeps, threads)
+        t_mt = (time.perf_counter() - t0) / sweeps
+        out["all_cores"] = {"value": w * w / t_mt / 1e6, "unit": "Mcells/s per Jacobi iter", "cores": threads,
+                            "kind": "port", "sample": "%d sweeps of the pressure solve, POSIX threads over row bands "
+                                                      "(fo_diffuse_mt), %d threads of %d host cores" % (sweeps, threads, cores)}
     return out
 
 
@@ -183,26 +240,54 @@ def main():
     grid = a.grid or (4096 if world == 1 else 8192)
     n = grid - 2
     cells = grid * grid
+    exchange = a.exchange if a.exchange != "auto" else ("rccl" if a.backend == "nccl" else "torch")
 
-    def run(n_, steps, warmup):
-        fields = initialize_parameters(n_, seed=a.seed)     # same seed on every rank
+    def make(n_):
         s = SlabSolver(n_, rank=rank, nranks=world, halo=a.halo, jacobi=a.variant,
-                       storage=1 if a.dtype == "f16" else 0)
+                       storage=1 if a.dtype == "f16" else 0, exchange=exchange)
         if a.tb_sweeps:
             s.set_param(0, a.tb_sweeps)
         if a.tb_rows:
             s.set_param(1, a.tb_rows)
+        if a.fast_division >= 0:
+            s.set_param(3, a.fast_division)
+        return s
+
+    def run(n_, steps, warmup):
+        fields = initialize_parameters(n_, seed=a.seed)     # same seed on every rank
+        s = make(n_)
         s.load_global(**fields)
-        out = measure(s, dist, world, steps, warmup, a.iters, (n_ + 2) ** 2)
-        calls = dict(s.exchange.calls) if s.exchange else None
+        out = measure(s, dist, world, steps, warmup, a.iters)
+        calls = s.exchange_calls()
         s.close()
         return out, fields, calls
+
+    def run_ordinary(n_, steps, warmup):
+        fields = initialize_parameters(n_, seed=a.seed)
+        s = make(n_)
+        s.load_global(**fields)
+        out = measure_ordinary(s, fields, steps, warmup, a.iters)
+        s.close()
+        return out
+
+    def rates(elapsed, jac_ms, prs_ms, t, steps, cells_):
+        t_sweep = jac_ms * 1e-3 / max(t["sweeps"], 1)
+        t_psweep = prs_ms * 1e-3 / max(t["pressure_sweeps"], 1)
+        return {"value": cells_ / t_psweep / 1e6, "ms_per_step": elapsed * 1e3 / steps,
+                "us_per_jacobi_sweep": t_psweep * 1e6, "all_solves_value": cells_ / t_sweep / 1e6,
+                "all_solves_us_per_jacobi_sweep": t_sweep * 1e6, "t_sweep": t_sweep}
+
+    if a.only_ordinary:
+        e, j, p, t, copy_ms = run_ordinary(n, a.steps, a.warmup)
+        r = rates(e, j, p, t, a.steps, cells)
+        print(json.dumps({"value_ordinary_data": r, "copy_ms_per_step": copy_ms}), flush=True)
+        return
 
     if a.check and world > 1:
         # rehearsal aid: W+K steps on slabs vs the same steps in one context on this rank's GPU
         import fluidsimulationcuda_amd as F
         fields = initialize_parameters(n, seed=a.seed)
-        s = SlabSolver(n, rank=rank, nranks=world, halo=a.halo, jacobi=a.variant)
+        s = make(n)
         s.load_global(**fields)
         s.step(1, use_sources=True, iters=a.iters)
         s.step(2, iters=a.iters)
@@ -218,31 +303,33 @@ def main():
                     sys.exit("rank %d: %s differs between %d slabs and one context" % (rank, k, world))
         if rank == 0:
             print("check ok: %d slabs bit-identical to one context at %dx%d" % (world, grid, grid), file=sys.stderr)
-    (elapsed, jac_ms, sweeps, launches, field_launches, prs_ms, prs_sweeps), fields, calls = run(n, a.steps, a.warmup)
-    ms_step = elapsed * 1e3 / a.steps
-    t_sweep = jac_ms * 1e-3 / max(sweeps, 1)             # all 200 sweeps of the step
-    t_psweep = prs_ms * 1e-3 / max(prs_sweeps, 1)        # the pressure solves: SURVEY.md 8(d)'s definition of the metric
-    mcells = cells / t_psweep / 1e6
+    (elapsed, jac_ms, prs_ms, t), fields, calls = run(n, a.steps, a.warmup)
+    r = rates(elapsed, jac_ms, prs_ms, t, a.steps, cells)
+    ms_step, t_sweep = r["ms_per_step"], r["t_sweep"]
+    sweeps, field_launches = t["sweeps"], t["jacobi_field_launches"]
     bpc = BYTES_PER_CELL_SWEEP // (2 if a.dtype == "f16" else 1)
     achieved = bpc * cells / t_sweep / 1e9
-    launches = max(launches, 1)
+    launches = max(t["jacobi_launches"], 1)
     per_launch = sweeps / launches                       # field-sweeps per launch (a batched launch sweeps 3 fields)
     kernel_name = ("k_jacobi_tb (8 or 16 sweeps + set_bnd per launch, up to 3 fields per launch; %.1f launches/step)"
                    % (launches / a.steps)) if a.variant == 3 else "k_jacobi_%s (one sweep + fused set_bnd)" % KERNELS[a.variant]
+    arith = "fp32" if a.dtype == "f32" else "fp16 storage, fp32 arithmetic"
     line = {
-        "metric": "Mcells/s per Jacobi iter", "value": mcells, "unit": "Mcells/s",
+        "metric": "Mcells/s per Jacobi iter", "value": r["value"], "unit": "Mcells/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32" if a.dtype == "f32" else "f16 storage, f32 arithmetic",
-        "data": "synthetic (initializeParameters recipe, PCG64 seed %d)" % a.seed,
-        "config": {"workload": "%dx%d grid, full vel_step+dens_step, %d Jacobi sweeps/solve (200/step), fp32"
-                               % (grid, grid, a.iters),
+        "data": "synthetic (initializeParameters recipe, PCG64 seed %d; sources at step 0 only, as the reference's loop: "
+                "the timed steps run on decaying fields -- see value_ordinary_data)" % a.seed,
+        "config": {"workload": "%dx%d grid, full vel_step+dens_step, %d Jacobi sweeps/solve (200/step), %s"
+                               % (grid, grid, a.iters, arith),
                    "grid": grid, "iters": a.iters, "jacobi_kernel": KERNELS[a.variant],
-                   "parallelism": "1 GPU" if world == 1 else "row slabs x%d, %s halo rows" % (
-                       world, "RCCL" if a.backend == "nccl" else a.backend + " (host-staged rehearsal)")},
+                   "parallelism": "1 GPU" if world == 1 else "row slabs x%d, halo rows by %s" % (
+                       world, ("RCCL, library-native exchange" if exchange == "rccl" else "RCCL via torch.distributed")
+                       if a.backend == "nccl" else a.backend + " (host-staged rehearsal)")},
         "ms_per_sim_step": ms_step,
-        "us_per_jacobi_sweep": t_psweep * 1e6,
-        "all_solves": {"value": cells / t_sweep / 1e6, "unit": "Mcells/s", "us_per_jacobi_sweep": t_sweep * 1e6,
+        "us_per_jacobi_sweep": r["us_per_jacobi_sweep"],
+        "all_solves": {"value": r["all_solves_value"], "unit": "Mcells/s", "us_per_jacobi_sweep": t_sweep * 1e6,
                        "note": "the same rate over all 200 sweeps of the step (3 diffusions, whose exact division "
                                "by 1+4a costs more than the pressure solve's multiply by 1/4, + 2 pressure solves)"},
         "step_algorithmic_GBps": BYTES_PER_CELL_STEP // (2 if a.dtype == "f16" else 1) * cells / (ms_step * 1e-3) / 1e9,
@@ -251,27 +338,67 @@ def main():
                      "frac": achieved / world / HBM_PEAK_GBS, "traffic": None,
                      "launches": launches, "mean_launch_us": jac_ms * 1e3 / launches,
                      "algorithmic_bytes_per_launch": bpc * (cells // world) * per_launch,
-                     "note": ("per GPU: algorithmic 12 B/cell/sweep x %d cells x %.1f field-sweeps per launch / mean "
-                              "launch time, HIP events on the solver's stream over %d timed launches"
-                              % (cells // world, per_launch, launches)) + (
-                                 "; temporal blocking keeps the intermediate sweeps on chip, so the algorithmic "
-                                 "rate may exceed the HBM peak -- frac_compulsory prices each launch at its own "
-                                 "compulsory traffic (read x, x0, write x once per field = 12 B/cell)" if a.variant == 3 else "")},
+                     "note": ("SURVEY.md 8(d)'s definition -- per GPU: algorithmic 12 B/cell/sweep x %d cells x %.1f "
+                              "field-sweeps per launch / mean launch time, HIP events on the solver's stream over %d "
+                              "timed launches" % (cells // world, per_launch, launches)) + (
+                                 ".  Temporal blocking keeps the intermediate sweeps on chip, so this ALGORITHMIC rate "
+                                 "exceeds the HBM peak and `frac` is not a fraction of anything the hardware does: "
+                                 "`frac_compulsory` prices each launch at its own compulsory traffic (read x, x0, "
+                                 "write x once per field = 12 B/cell), and `roofline_actual` states what the launches "
+                                 "are bound by and how close they come (<= 1)" if a.variant == 3 else "")},
     }
     line["roofline"]["frac_compulsory"] = bpc * (cells / world) * field_launches / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-    tr = pmc_traffic("k_jacobi_%s" % KERNELS[a.variant], grid) if world == 1 else None
-    if tr:
-        line["roofline"]["traffic"] = tr[0]
-        line["roofline"]["traffic_source"] = "profiles/" + tr[1]
+    pmc = pmc_summary(grid) if world == 1 else None
+    if pmc:
+        summary, src = pmc
+        kern = "k_jacobi_%s" % KERNELS[a.variant]
+        traffic = pmc_per_launch(summary, kern, "hbm_bytes_per_launch")
+        valu = pmc_per_launch(summary, kern, "valu_insts_per_launch")
+        mean_us = jac_ms * 1e3 / launches
+        if traffic:
+            line["roofline"]["traffic"] = traffic
+            line["roofline"]["traffic_source"] = "profiles/" + src
+        if traffic and valu:
+            hbm_frac = traffic / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+            valu_rate = valu / SIMDS / mean_us
+            valu_frac = valu_rate / VALU_PEAK_PER_SIMD_US
+            line["roofline_actual"] = {
+                "bound": "valu_issue" if valu_frac >= hbm_frac else "hbm",
+                "achieved": valu_rate if valu_frac >= hbm_frac else traffic / (mean_us * 1e-6) / 1e9,
+                "peak": VALU_PEAK_PER_SIMD_US if valu_frac >= hbm_frac else HBM_PEAK_GBS,
+                "unit": "wave-instructions/us/SIMD" if valu_frac >= hbm_frac else "GB/s",
+                "frac": max(valu_frac, hbm_frac),
+                "valu_issue": {"achieved": valu_rate, "peak": VALU_PEAK_PER_SIMD_US, "frac": valu_frac,
+                               "valu_insts_per_launch": valu},
+                "hbm": {"achieved": traffic / (mean_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "frac": hbm_frac,
+                        "bytes_per_launch": traffic},
+                "note": "mean Jacobi launch of the timed steps (HIP events) against both ceilings: vector instructions per "
+                        "launch (SQ_INSTS_VALU) over the 1024 SIMDs vs what one SIMD sustains of this instruction mix "
+                        "(tools/ubench/valu_peak.hip), and HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) vs the 8 TB/s "
+                        "peak; counters from %s (the same command under rocprofv3, one --pmc pass per counter group)"
+                        % ("profiles/" + src)}
     if calls:
         line["exchanges_per_rank"] = {"halo": calls[0], "gather": calls[1], "max": calls[2]}
+    if world == 1 and not a.no_ordinary:
+        e2, j2, p2, t2, copy_ms = run_ordinary(n, a.steps, a.warmup)
+        r2 = rates(e2, j2, p2, t2, a.steps, cells)
+        line["value_ordinary_data"] = {
+            "value": r2["value"], "unit": "Mcells/s", "us_per_jacobi_sweep": r2["us_per_jacobi_sweep"],
+            "all_solves_value": r2["all_solves_value"], "all_solves_us_per_jacobi_sweep": r2["all_solves_us_per_jacobi_sweep"],
+            "ms_per_step": r2["ms_per_step"], "source_copies_ms_per_step": copy_ms,
+            "frac_compulsory": bpc * cells * t2["jacobi_field_launches"] / (j2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "same grid and kernels; the three source fields are re-injected before every step (device-to-device "
+                    "copies, included in ms_per_step, %.3f ms of it) and consumed by add_source, so all fields keep "
+                    "ordinary magnitudes instead of decaying towards zero" % copy_ms}
     if world == 1 and not a.no_scaling_base and grid != 8192:
-        (e2, j2, s2, _l2, _f2, p2, ps2), _, _ = run(8190, max(a.steps // 4, 3), 2)
-        ts2 = p2 * 1e-3 / max(ps2, 1)
-        line["scaling_base"] = {"workload": "8192x8192 on 1 GPU", "value": 8192 * 8192 / ts2 / 1e6, "unit": "Mcells/s",
-                                "ms_per_step": e2 * 1e3 / max(a.steps // 4, 3),
-                                "all_solves_value": 8192 * 8192 / (j2 * 1e-3 / max(s2, 1)) / 1e6,
-                                "roofline_frac": BYTES_PER_CELL_SWEEP * 8192 * 8192 / (j2 * 1e-3 / max(s2, 1)) / 1e9 / HBM_PEAK_GBS}
+        steps2 = max(a.steps // 4, 3)
+        (e2, j2, p2, t2), _, _ = run(8190, steps2, 2)
+        r2 = rates(e2, j2, p2, t2, steps2, 8192 * 8192)
+        line["scaling_base"] = {"workload": "8192x8192 on 1 GPU", "value": r2["value"], "unit": "Mcells/s",
+                                "ms_per_step": r2["ms_per_step"], "all_solves_value": r2["all_solves_value"],
+                                "roofline_frac": BYTES_PER_CELL_SWEEP * 8192 * 8192 / r2["t_sweep"] / 1e9 / HBM_PEAK_GBS,
+                                "frac_compulsory": BYTES_PER_CELL_SWEEP * 8192 * 8192 * t2["jacobi_field_launches"]
+                                / (j2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(n, fields, a.iters)
     if rank == 0:

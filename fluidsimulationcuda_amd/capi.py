@@ -19,6 +19,7 @@ PARAM_TB_MAX_SWEEPS, PARAM_TB_ROWS, PARAM_HALO, PARAM_TB_FAST_DIVISION, PARAM_TB
 PARAM_TB_LANE_COLUMNS = 6
 PARAM_TB_T16_MIN_CELLS = 7
 XCHG_HALO, XCHG_GATHER, XCHG_MAX, XCHG_MAX_BEGIN, XCHG_MAX_END = 0, 1, 2, 3, 4
+RCCL_ID_BYTES = 128
 FIELD_NAMES = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev", "tmp0", "tmp1", "tmp2")
 
 
@@ -91,6 +92,12 @@ SIGNATURES = {
     "fluid_timing_read": [_ctx, C.POINTER(Timing), _i],
     "fluid_op_diffuse_tol": [_ctx, _i, _i, _i, _f, _f, _f, _i, _i, C.POINTER(_i), C.POINTER(_f)],
     "fluid_set_exchange": [_ctx, EXCHANGE_FN, C.c_void_p],
+    "fluid_exchange_now": [_ctx, _i, C.POINTER(_i), _i, _i],
+    "fluid_rccl_unique_id": [C.c_void_p, C.c_size_t],
+    "fluid_exchange_rccl_attach": [_ctx, C.c_void_p, C.c_size_t],
+    "fluid_exchange_rccl_attach_comm": [_ctx, C.c_void_p],
+    "fluid_exchange_rccl_detach": [_ctx],
+    "fluid_exchange_rccl_calls": [_ctx, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)],
 }
 # symbols with a non-status return type
 OTHER_SYMBOLS = {"fluid_last_error": (C.c_char_p, []), "fluid_arena_bytes": (C.c_size_t, [_i]),

@@ -1,0 +1,85 @@
+// fluid_ctx.h -- the context behind include/fluid_amd.h's opaque fluid_ctx, shared by the orchestrator
+// (fluid_solver.hip) and the native RCCL exchange (fluid_exchange_rccl.hip).  Private to csrc/.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/fluid_amd.h"
+#include "fluid_kernels.h"
+
+namespace fluid_detail {
+int fail(int code, const char* fmt, ...);      // records the calling thread's error string, returns `code`
+struct RcclExchange;                            // fluid_exchange_rccl.hip
+void rccl_release(RcclExchange* x);
+}  // namespace fluid_detail
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fluid_detail::fail(e_ == hipErrorOutOfMemory ? FLUID_E_NOMEM : FLUID_E_HIP, "%s: %s",   \
+                                      #expr, hipGetErrorString(e_));                                       \
+    } while (0)
+
+#define TRY(expr)                        \
+    do {                                 \
+        int rc_ = (expr);                \
+        if (rc_ != FLUID_OK) return rc_; \
+    } while (0)
+
+struct fluid_ctx {
+    int n = 0, w = 0, pitch = 0;
+    size_t field_floats = 0;
+    char* arena = nullptr;
+    bool own_arena = false;
+    int st = fluid::STORAGE_F32;          // field storage type
+    size_t esz = 4;                       // bytes per stored element
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void* f[FLUID_NFIELDS] = {};
+    size_t field_bytes = 0;
+    unsigned int* d_scalar = nullptr;     // device word for the reductions
+    unsigned int* tiles = nullptr;        // 3 x tile_rows x tile_pitch words: |x0| minima per tile for division mode 3
+    unsigned int* h_scalar = nullptr;     // pinned host mirror
+    hipEvent_t scalar_ready = nullptr;    // recorded behind the scalar's device-to-host copy
+    int variant = fluid::JACOBI_TB;
+    int tb_max_t = 16, tb_rows = 0, num_cu = 256;   // temporal blocking: sweeps/launch cap, rows/strip (0 = auto)
+    long long tb_min_cells = 0;                    // smaller slabs use single-sweep launches (never faster since the 2-column lanes)
+    long long tb_t16_min_cells = -1;               // >= 0: 16-sweep launches on every slab of at least this many cells (tests, tuning);
+                                                   // -1: the measured rule of pick_sweeps()
+    bool defer_zero_source = true;                 // see settle()
+    bool in_halo_exchange = false;
+    int tb_nv = 2;                                 // columns per lane of the fused kernel (2: 4 waves/SIMD; 4: 2 waves/SIMD)
+    int tb_edge_pct = 40;                          // strip height of the two edge windows, % of the others'
+    int fast_div = 2;                              // 0: always divide; 2 (default): division modes 2 / 4 (each beta proven on the
+                                                   // device first); 1: also the two-term mode 3 where |x0| allows it -- exact as well,
+                                                   // 10-17 % faster on a solve of its own, no faster inside a step
+    // slab decomposition
+    int rank = 0, nranks = 1, own0 = 1, own1 = 1, min_slab = 0, halo = 1;
+    int reach[FLUID_NFIELDS] = {};            // see "row-slab bookkeeping" below
+    bool zero[FLUID_NFIELDS] = {};            // field is all +0 by definition; its memory is NOT (yet) zeroed
+    bool pend[FLUID_NFIELDS] = {};            // field owes itself `+ pend_inc[f]` in every cell (deferred add_source of a zero source)
+    float pend_inc[FLUID_NFIELDS] = {};
+    fluid_exchange_fn xchg = nullptr;
+    void* xchg_user = nullptr;
+    fluid_detail::RcclExchange* rccl = nullptr;   // the library's own exchange, when attached (fluid_exchange_rccl_attach)
+    // timing
+    bool timing = false;
+    struct Ev { hipEvent_t a, b; int cat; bool pressure; };
+    std::vector<Ev> ev_pool;
+    size_t ev_used = 0;
+    double cat_ms[FLUID_TIMING_CATEGORIES] = {};
+    long long cat_calls[FLUID_TIMING_CATEGORIES] = {};
+    long long sweeps = 0, pending_sweeps = 0, launches = 0, field_launches = 0;
+    double pressure_ms = 0.0;                      // the part of cat_ms[DIFFUSION] spent in pressure solves (project())
+    long long pressure_sweeps = 0, pending_pressure_sweeps = 0;
+    bool in_pressure_solve = false;
+
+    bool valid_field(int id) const { return id >= 0 && id < FLUID_NFIELDS; }
+    void* row(int id, int r) const { return static_cast<char*>(f[id]) + (size_t)r * pitch * esz; }
+    int lo_all() const { return own0 - (rank == 0 ? 1 : 0); }          // owned rows incl. ghost row
+    int hi_all() const { return own1 + (rank == nranks - 1 ? 1 : 0); }
+};
+

@@ -16,10 +16,9 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/fluid_amd.h"
-#include "fluid_kernels.h"
+#include "fluid_ctx.h"
 
-namespace {
+namespace fluid_detail {
 
 thread_local std::string g_err;
 
@@ -34,77 +33,18 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            return fail(e_ == hipErrorOutOfMemory ? FLUID_E_NOMEM : FLUID_E_HIP, "%s: %s",   \
-                        #expr, hipGetErrorString(e_));                                       \
-    } while (0)
+}  // namespace fluid_detail
 
-#define TRY(expr)                        \
-    do {                                 \
-        int rc_ = (expr);                \
-        if (rc_ != FLUID_OK) return rc_; \
-    } while (0)
+namespace {
+
+using fluid_detail::fail;
+using fluid_detail::g_err;
 
 constexpr size_t kControlBytes = 256;   // tail of the arena: reduction scalar (+0), division-proof counter (+8)
 constexpr int kMaxN = 65533;     // one grid row per blockIdx.y in the pointwise kernels (HIP: gridDim.y <= 65535 = N + 2);
                                  // 65535^2 x 9 fields is 155 GB of the 288 GB, so nothing practical is cut off
 
 }  // namespace
-
-struct fluid_ctx {
-    int n = 0, w = 0, pitch = 0;
-    size_t field_floats = 0;
-    char* arena = nullptr;
-    bool own_arena = false;
-    int st = fluid::STORAGE_F32;          // field storage type
-    size_t esz = 4;                       // bytes per stored element
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    void* f[FLUID_NFIELDS] = {};
-    size_t field_bytes = 0;
-    unsigned int* d_scalar = nullptr;     // device word for the reductions
-    unsigned int* tiles = nullptr;        // 3 x tile_rows x tile_pitch words: |x0| minima per tile for division mode 3
-    unsigned int* h_scalar = nullptr;     // pinned host mirror
-    hipEvent_t scalar_ready = nullptr;    // recorded behind the scalar's device-to-host copy
-    int variant = fluid::JACOBI_TB;
-    int tb_max_t = 16, tb_rows = 0, num_cu = 256;   // temporal blocking: sweeps/launch cap, rows/strip (0 = auto)
-    long long tb_min_cells = 0;                    // smaller slabs use single-sweep launches (never faster since the 2-column lanes)
-    long long tb_t16_min_cells = -1;               // >= 0: 16-sweep launches on every slab of at least this many cells (tests, tuning);
-                                                   // -1: the measured rule of pick_sweeps()
-    bool defer_zero_source = true;                 // see settle()
-    bool in_halo_exchange = false;
-    int tb_nv = 2;                                 // columns per lane of the fused kernel (2: 4 waves/SIMD; 4: 2 waves/SIMD)
-    int tb_edge_pct = 40;                          // strip height of the two edge windows, % of the others'
-    int fast_div = 1;                              // 0: always divide; 1: division modes 2/3/4 allowed (each beta proven on the
-                                                   // device first); 2: as 1 without the guarded two-term mode 3
-    // slab decomposition
-    int rank = 0, nranks = 1, own0 = 1, own1 = 1, min_slab = 0, halo = 1;
-    int reach[FLUID_NFIELDS] = {};            // see "row-slab bookkeeping" below
-    bool zero[FLUID_NFIELDS] = {};            // field is all +0 by definition; its memory is NOT (yet) zeroed
-    bool pend[FLUID_NFIELDS] = {};            // field owes itself `+ pend_inc[f]` in every cell (deferred add_source of a zero source)
-    float pend_inc[FLUID_NFIELDS] = {};
-    fluid_exchange_fn xchg = nullptr;
-    void* xchg_user = nullptr;
-    // timing
-    bool timing = false;
-    struct Ev { hipEvent_t a, b; int cat; bool pressure; };
-    std::vector<Ev> ev_pool;
-    size_t ev_used = 0;
-    double cat_ms[FLUID_TIMING_CATEGORIES] = {};
-    long long cat_calls[FLUID_TIMING_CATEGORIES] = {};
-    long long sweeps = 0, pending_sweeps = 0, launches = 0, field_launches = 0;
-    double pressure_ms = 0.0;                      // the part of cat_ms[DIFFUSION] spent in pressure solves (project())
-    long long pressure_sweeps = 0, pending_pressure_sweeps = 0;
-    bool in_pressure_solve = false;
-
-    bool valid_field(int id) const { return id >= 0 && id < FLUID_NFIELDS; }
-    void* row(int id, int r) const { return static_cast<char*>(f[id]) + (size_t)r * pitch * esz; }
-    int lo_all() const { return own0 - (rank == 0 ? 1 : 0); }          // owned rows incl. ghost row
-    int hi_all() const { return own1 + (rank == nranks - 1 ? 1 : 0); }
-};
 
 namespace {
 
@@ -125,7 +65,7 @@ int check_fields(const fluid_ctx* c, std::initializer_list<int> ids)
 
 int exchange(fluid_ctx* c, int kind, std::initializer_list<int> fields, int depth, float* scalar = nullptr)
 {
-    if (c->nranks == 1) return FLUID_OK;
+    if (c->nranks == 1 && !c->rccl) return FLUID_OK;      // (a one-rank communicator may be attached: it is then exercised)
     if (!c->xchg) return fail(FLUID_E_COMM, "multi-GPU context without an exchange callback");
     std::vector<int> ids(fields);
     // the same field listed twice (self-advection) is exchanged once
@@ -1087,6 +1027,8 @@ int fluid_destroy(fluid_ctx* c)
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
     }
+    fluid_detail::rccl_release(c->rccl);
+    c->rccl = nullptr;
     if (c->h_scalar) (void)hipHostFree(c->h_scalar);
     if (c->tiles) (void)hipFree(c->tiles);
     if (c->scalar_ready) (void)hipEventDestroy(c->scalar_ready);
@@ -1237,6 +1179,25 @@ int fluid_set_exchange(fluid_ctx* c, fluid_exchange_fn fn, void* user)
     TRY(check_ctx(c));
     c->xchg = fn;
     c->xchg_user = user;
+    return FLUID_OK;
+}
+
+int fluid_exchange_now(fluid_ctx* c, int kind, const int* fields, int nfields, int depth)
+{
+    TRY(check_ctx(c));
+    if (!c->xchg) return fail(FLUID_E_COMM, "no exchange installed");
+    if (kind != FLUID_XCHG_HALO && kind != FLUID_XCHG_GATHER) return fail(FLUID_E_INVALID, "fluid_exchange_now moves rows: HALO or GATHER");
+    if (nfields < 0 || (nfields > 0 && !fields)) return fail(FLUID_E_INVALID, "bad field list");
+    for (int k = 0; k < nfields; ++k) {
+        TRY(check_fields(c, {fields[k]}));
+        TRY(settle(c, fields[k]));             // the caller is about to look at the rows: no increment may stay pending
+    }
+    c->in_halo_exchange = true;
+    const int rc = c->xchg(c->xchg_user, kind, fields, nfields, depth, nullptr);
+    c->in_halo_exchange = false;
+    if (rc != 0) return fail(FLUID_E_COMM, "exchange failed (kind %d, rc %d)", kind, rc);
+    for (int k = 0; k < nfields; ++k)
+        c->reach[fields[k]] = kind == FLUID_XCHG_GATHER ? kEverywhere : std::max(c->reach[fields[k]], depth);
     return FLUID_OK;
 }
 

@@ -44,12 +44,14 @@ class TorchExchange:
         self.stream = stream        # torch.cuda.Stream the solver's kernels run on (None: CPU tensors)
         self.lo, self.hi = slab_rows(n, rank, nranks)
         self.calls = {capi.XCHG_HALO: 0, capi.XCHG_GATHER: 0, capi.XCHG_MAX: 0}
-        self.scalar = None          # 1-element float32 view of the solver's device reduction scalar
-        self._reduced_on_device = False
         # RCCL moves device memory directly.  gloo cannot, so device rows are
         # staged through host buffers: used only to rehearse the multi-process
         # path on a box with fewer GPUs than ranks (tests, bench --backend gloo).
         self.staged = fields(0).is_cuda and dist.get_backend(group) != "nccl"
+        # Where the velocity bound is reduced is fixed here, identically on every rank (it follows from the
+        # backend alone): on the device word, in place, when the transport addresses device memory (set_scalar),
+        # else on the host at END.  Ranks that disagreed would issue different collective sequences and hang.
+        self.scalar = None          # 1-element int32 view of the solver's device reduction word
 
     def _peer(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
@@ -65,17 +67,13 @@ class TorchExchange:
     def _dispatch(self, kind, ids, depth, scalar):
         if kind == capi.XCHG_MAX_BEGIN:
             self.calls[capi.XCHG_MAX] += 1
-            self._reduced_on_device = False
-            if not self.staged and self.scalar is not None:
-                try:
-                    # non-negative floats: MAX on the device word, in place, on the solver's stream
-                    dist.all_reduce(self.scalar, op=dist.ReduceOp.MAX, group=self.group)
-                    self._reduced_on_device = True
-                except RuntimeError:
-                    self.scalar = None       # this transport cannot do it: reduce on the host at END from now on
+            if self.scalar is not None:
+                # the word holds the bit pattern of a non-negative float (the kernel's atomicMax works on it as an
+                # unsigned integer): MAX over the patterns is exact, order independent and total even for NaN
+                dist.all_reduce(self.scalar, op=dist.ReduceOp.MAX, group=self.group)
             return None
         if kind == capi.XCHG_MAX_END:
-            return scalar if self._reduced_on_device else self.maximum(scalar)
+            return scalar if self.scalar is not None else self.maximum(scalar)
         self.calls[kind] += 1
         if kind == capi.XCHG_HALO:
             return self.halo(ids, depth)
@@ -131,11 +129,17 @@ class TorchExchange:
                 else:
                     dist.broadcast(f[lo:hi], src=self._peer(r), group=self.group)
 
+    def set_scalar(self, word):
+        """`word`: 1-element int32 tensor aliasing the solver's device reduction word.  Taken only when the
+        transport addresses device memory (backend nccl) -- the same decision on every rank."""
+        self.scalar = word if (word is not None and word.is_cuda and not self.staged) else None
+
     def maximum(self, value):
-        dev = "cpu" if self.staged else self.fields(0).device
-        t = torch.tensor([value], dtype=torch.float32, device=dev)
+        dev = "cpu" if (self.staged or not self.fields(0).is_cuda) else self.fields(0).device
+        bits = int(np.float32(value).view(np.int32))       # non-negative floats order like their bit patterns
+        t = torch.tensor([bits], dtype=torch.int32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        return float(t.item())
+        return float(np.int32(t.item()).view(np.float32))
 
 
 class SlabSolver(FluidSolver):
@@ -144,7 +148,11 @@ class SlabSolver(FluidSolver):
     collectives order against them without host synchronisation."""
 
     def __init__(self, n, rank=None, nranks=None, halo=0, jacobi=capi.JACOBI_TB, device=None, group=None,
-                 storage=capi.STORAGE_F32, params=None):
+                 storage=capi.STORAGE_F32, params=None, exchange="torch"):
+        """exchange: "torch" -- rows move through torch.distributed (TorchExchange, a Python callback; works on
+        every backend, host-staged on gloo); "rccl" -- the library's own exchange (csrc/fluid_exchange_rccl.hip:
+        grouped ncclSend/ncclRecv on the solver's stream, no Python and no host wait in the path); its
+        communicator's id is handed round with one torch.distributed broadcast."""
         if rank is None:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         if nranks is None:
@@ -176,7 +184,22 @@ class SlabSolver(FluidSolver):
         self._views = [self.arena[k * self._fb:(k + 1) * self._fb].view(dt).view(n + 2, self.pitch)
                        for k in range(capi.NFIELDS)]
         self.exchange = None
-        if nranks > 1:
+        self.native_exchange = False
+        if nranks > 1 and exchange == "rccl":
+            import ctypes as C
+            on_dev = dist.get_backend(group) == "nccl"
+            uid = torch.zeros(capi.RCCL_ID_BYTES, dtype=torch.uint8, device=self.device if on_dev else "cpu")
+            if rank == 0:
+                buf = (C.c_ubyte * capi.RCCL_ID_BYTES)()
+                capi.check(L.fluid_rccl_unique_id(buf, capi.RCCL_ID_BYTES))
+                uid.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast(uid, src=src, group=group)
+            raw = bytes(uid.cpu().numpy().tobytes())
+            with torch.cuda.device(self.device):
+                capi.check(L.fluid_exchange_rccl_attach(self._h, raw, len(raw)))
+            self.native_exchange = True
+        elif nranks > 1:
             if dist.get_backend(group) == "nccl":
                 # batched send/recv must not be the first operation on a NCCL group: start with an all-reduce
                 hello = torch.ones(1, device=self.device)
@@ -184,7 +207,7 @@ class SlabSolver(FluidSolver):
                 torch.cuda.synchronize(self.device)
             self.exchange = TorchExchange(self.field_tensor, n, rank, nranks, group, stream=self.torch_stream)
             off = self.scalar_ptr() - self.arena.data_ptr()
-            self.exchange.scalar = self.arena[off:off + 4].view(torch.float32)
+            self.exchange.set_scalar(self.arena[off:off + 4].view(torch.int32))
             self.set_exchange(self.exchange)
 
     def field_tensor(self, fid):
@@ -212,7 +235,17 @@ class SlabSolver(FluidSolver):
         an in-place all-gather of the slabs, then one download (bit preserving)."""
         fid = capi.FIELD_NAMES.index(field) if isinstance(field, str) else int(field)
         if self.nranks > 1:
-            self.synchronize()
-            self.exchange(capi.XCHG_GATHER, [fid], 0, None)
+            import ctypes as C
+            ids = (C.c_int * 1)(fid)
+            capi.check(capi.lib().fluid_exchange_now(self._h, capi.XCHG_GATHER, ids, 1, 0))
             torch.cuda.synchronize(self.device)
         return self.download(fid)
+
+    def exchange_calls(self):
+        """{halo, gather, max} exchanges this rank has issued."""
+        if self.native_exchange:
+            import ctypes as C
+            h, g, m = C.c_longlong(), C.c_longlong(), C.c_longlong()
+            capi.check(capi.lib().fluid_exchange_rccl_calls(self._h, C.byref(h), C.byref(g), C.byref(m)))
+            return {capi.XCHG_HALO: h.value, capi.XCHG_GATHER: g.value, capi.XCHG_MAX: m.value}
+        return dict(self.exchange.calls) if self.exchange else None

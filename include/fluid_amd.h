@@ -55,12 +55,13 @@ enum {
     FLUID_PARAM_TB_MAX_SWEEPS = 0, /* most sweeps fused per launch by FLUID_JACOBI_TB: 16 (default), 8, 4 or 2 */
     FLUID_PARAM_TB_ROWS = 1,       /* output rows per wave strip of FLUID_JACOBI_TB; 0 = auto          */
     FLUID_PARAM_HALO = 2,          /* multi-GPU ghost-zone depth (clamped to slab height - 1)          */
-    FLUID_PARAM_TB_FAST_DIVISION = 3 /* 1 (default): FLUID_JACOBI_TB may replace x/beta by an exactly equivalent
-                                      reciprocal form -- one float multiply when beta is a power of two, else a
-                                      guarded two-term float reciprocal (fma(x, hi, x*lo), quotients in
-                                      (0, 2^-100) redone in double), else a double multiply -- each after proving
-                                      the equivalence for that beta on all 2^32 float inputs on the device;
-                                      2: the same without the two-term form; 0: always divide            */
+    FLUID_PARAM_TB_FAST_DIVISION = 3 /* how FLUID_JACOBI_TB may replace x/beta by an exactly equivalent reciprocal form,
+                                      each after proving the equivalence for that beta on all 2^32 float inputs on
+                                      the device.  2 (default): one float multiply when beta is a power of two (and
+                                      alpha 1), else a double-precision multiply.  1: in addition the two-term float
+                                      reciprocal fma(x, hi, x*lo) in waves whose right-hand side is nowhere smaller
+                                      than beta * 2^-72 (which bounds every dividend away from the range where that
+                                      form is one ulp off).  0: always divide                              */
     ,FLUID_PARAM_TB_EDGE_ROWS_PCT = 5 /* strip height of the two windows that carry the ghost columns, in % of
                                       the interior windows' (default 40; 0 = same): load balance only  */
     ,FLUID_PARAM_TB_LANE_COLUMNS = 6 /* columns per lane of FLUID_JACOBI_TB: 2 (default; thin waves, 4 per SIMD)
@@ -230,6 +231,30 @@ enum { FLUID_XCHG_HALO = 0, FLUID_XCHG_GATHER = 1, FLUID_XCHG_MAX = 2, FLUID_XCH
 typedef int (*fluid_exchange_fn)(void *user, int kind, const int *fields, int nfields,
                                  int depth, float *scalar);
 int fluid_set_exchange(fluid_ctx *ctx, fluid_exchange_fn fn, void *user);
+/* Runs the installed exchange now for the listed fields (HALO with `depth` rows, or GATHER): how a caller collects a
+ * whole field on every rank, and how the transport can be exercised on its own. */
+int fluid_exchange_now(fluid_ctx *ctx, int kind, const int *fields, int nfields, int depth);
+
+/* ---- the library's own exchange: RCCL over xGMI, no host in the path ------------------------------------
+ * north_star: "one-row ghost cells exchanged via RCCL Sendrecv over xGMI" (the reference is single-device:
+ * naivePar/FluidParallelBlockPerElement-Naive.cu:351-355 only ever selects device 0).  Halo rows travel as grouped
+ * ncclSend/ncclRecv between neighbouring slabs, the advect fall-back as grouped ncclBroadcast, the velocity bound
+ * as an in-place ncclAllReduce(max) on the device scalar; everything is enqueued on the context's stream.
+ * librccl is bound at run time (an RCCL the process already holds is reused; else $FLUID_RCCL_LIB; else the
+ * system's), so single-GPU users need none.
+ *   fluid_rccl_unique_id():       one rank calls it and hands the FLUID_RCCL_ID_BYTES bytes to all others (any way)
+ *   fluid_exchange_rccl_attach(): every rank, with its context (rank / nranks from fluid_create_ex) and that id, on
+ *                                 the thread whose current HIP device is the context's: creates the communicator,
+ *                                 runs one all-reduce and one send/receive probe, installs the exchange
+ *   ..._attach_comm():            the same on a communicator (ncclComm_t) the caller owns
+ *   ..._detach():                 removes it (and destroys a communicator the library created)
+ *   ..._calls():                  exchanges issued so far: halo, gather, max                                  */
+#define FLUID_RCCL_ID_BYTES 128
+int fluid_rccl_unique_id(void *id, size_t bytes);
+int fluid_exchange_rccl_attach(fluid_ctx *ctx, const void *id, size_t bytes);
+int fluid_exchange_rccl_attach_comm(fluid_ctx *ctx, void *nccl_comm);
+int fluid_exchange_rccl_detach(fluid_ctx *ctx);
+int fluid_exchange_rccl_calls(fluid_ctx *ctx, long long *halo, long long *gather, long long *max);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,7 @@
  * Layout: one field = (n+2)*(n+2) floats, row-major, cell (col j, row i) at
  * j + i*(n+2); ghost ring at index 0 and n+1 (FluidSequential.c:95,250-258).
  */
+#include <pthread.h>
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
@@ -122,6 +123,66 @@ int fo_diffuse(int n, int b, float *x, const float *x0, float alpha, float beta,
     if (cur != x) memcpy(x, cur, cells * sizeof(float));
     free(scratch);
     return 0;
+}
+
+/* The same solve with every sweep split into row bands over `threads` POSIX threads (bench.py's
+ * all-cores CPU baseline; the reference itself is single-threaded).  A sweep reads only the previous
+ * sweep's field, so bands are independent; a barrier separates the sweeps, thread 0 applies the
+ * boundary between two barriers.  Bit-identical to fo_diffuse.  Returns 0, -1 on OOM / thread failure. */
+struct fo_mt_job {
+    int n, b, iters, threads, id;
+    float *x, *scratch;
+    const float *x0;
+    float alpha, beta;
+    pthread_barrier_t *bar;
+};
+
+static void *fo_mt_worker(void *arg)
+{
+    const struct fo_mt_job *j = (const struct fo_mt_job *)arg;
+    const int lo = 1 + (int)(((long long)j->n * j->id) / j->threads);
+    const int hi = 1 + (int)(((long long)j->n * (j->id + 1)) / j->threads);
+    float *cur = j->x, *nxt = j->scratch;
+    for (int k = 0; k < j->iters; ++k) {
+        fo_jacobi_rows(j->n, cur, j->x0, nxt, j->alpha, j->beta, lo, hi);
+        pthread_barrier_wait(j->bar);
+        if (j->id == 0) fo_set_bnd(j->n, j->b, nxt);
+        pthread_barrier_wait(j->bar);
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    return NULL;
+}
+
+int fo_diffuse_mt(int n, int b, float *x, const float *x0, float alpha, float beta,
+                  int iters, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > n) threads = n;
+    if (threads > 256) threads = 256;
+    const size_t cells = ((size_t)n + 2) * ((size_t)n + 2);
+    float *scratch = (float *)malloc(cells * sizeof(float));
+    if (!scratch) return -1;
+    pthread_barrier_t bar;
+    if (pthread_barrier_init(&bar, NULL, (unsigned)threads) != 0) { free(scratch); return -1; }
+    struct fo_mt_job jobs[256];
+    pthread_t tid[256];
+    int started = 0, rc = 0;
+    for (int t = 0; t < threads; ++t) {
+        jobs[t] = (struct fo_mt_job){n, b, iters, threads, t, x, scratch, x0, alpha, beta, &bar};
+        if (t > 0 && pthread_create(&tid[t], NULL, fo_mt_worker, &jobs[t]) != 0) break;
+        ++started;
+    }
+    if (started != threads) {
+        /* cannot run short-handed (the barrier counts `threads`): the started workers are parked at the
+         * first barrier and nothing has been written yet beyond scratch; fail the process loudly */
+        abort();
+    }
+    fo_mt_worker(&jobs[0]);
+    for (int t = 1; t < threads; ++t) pthread_join(tid[t], NULL);
+    pthread_barrier_destroy(&bar);
+    if (iters & 1) memcpy(x, scratch, cells * sizeof(float));
+    free(scratch);
+    return rc;
 }
 
 /* ---- a5: semi-Lagrangian advection (FluidSequential.c:107-141) ---------- */

@@ -48,6 +48,7 @@ class Oracle:
             "fo_jacobi_sweep": (None, [i, i, _F, _F, _F, f, f]),
             "fo_diffuse": (i, [i, i, _F, _F, f, f, i]),
             "fo_jacobi_rows": (None, [i, _F, _F, _F, f, f, i, i]),
+            "fo_diffuse_mt": (i, [i, i, _F, _F, f, f, i, i]),
             "fo_advect": (None, [i, i, f, _F, _F, _F, _F]),
             "fo_divergence": (None, [i, _F, _F, _F, _F]),
             "fo_subtract_gradient": (None, [i, _F, _F, _F]),
@@ -79,19 +80,8 @@ class Oracle:
 
     def diffuse_threaded(self, b, x, x0, alpha, beta, iters, threads):
         """The same solve with every sweep split into row bands over `threads`
-        host threads (ctypes releases the GIL); bit-identical to diffuse()."""
-        from concurrent.futures import ThreadPoolExecutor
-        n = self._n(x)
-        edges = [1 + (n * k) // threads for k in range(threads + 1)]
-        cur, nxt = x, np.empty_like(x)
-        with ThreadPoolExecutor(threads) as pool:
-            for _ in range(iters):
-                list(pool.map(lambda k: self.lib.fo_jacobi_rows(n, cur, x0, nxt, alpha, beta, edges[k], edges[k + 1]),
-                              range(threads)))
-                self.lib.fo_set_bnd(n, b, nxt)
-                cur, nxt = nxt, cur
-        if cur is not x:
-            x[...] = cur
+        POSIX threads (fo_diffuse_mt); bit-identical to diffuse()."""
+        assert self.lib.fo_diffuse_mt(self._n(x), b, x, x0, alpha, beta, iters, threads) == 0
 
     def diffuse(self, b, x, x0, alpha, beta, iters=ITERS):
         assert self.lib.fo_diffuse(self._n(x), b, x, x0, alpha, beta, iters) == 0

@@ -221,12 +221,12 @@ def tb_schedule(iters, max_t):
     return out
 
 
-@pytest.mark.parametrize("lane_cols,max_t,fast_div", [(2, 16, 1), (2, 16, 0), (2, 8, 1), (2, 4, 1), (2, 2, 1), (4, 8, 1),
-                                                      (4, 4, 1), (4, 2, 1)])
+@pytest.mark.parametrize("lane_cols,max_t,fast_div", [(2, 16, 1), (2, 16, 2), (2, 16, 0), (2, 8, 1), (2, 8, 2), (2, 4, 2), (2, 2, 1),
+                                                      (4, 8, 1), (4, 8, 2), (4, 4, 2), (4, 2, 2)])
 @pytest.mark.parametrize("n", TB_SIZES)
 def test_temporal_blocking_matches_oracle(F, oracle, n, lane_cols, max_t, fast_div):
     """Every depth of the fused kernel, both forms (pressure: alpha 1, beta 4; general: the exact
-    reciprocal division, or true division with fast_div = 0), on window / strip / wall edge sizes.
+    reciprocal divisions of fast_div = 1 / 2, or true division with fast_div = 0), on window / strip / wall edge sizes.
     The launch count is asserted so that a silently shallower schedule fails: 16-sweep launches are
     normally reserved for grids of 8 M cells and more (PARAM_TB_T16_MIN_CELLS forces them here)."""
     from fluidsimulationcuda_amd import capi
@@ -344,7 +344,7 @@ def test_two_term_division_only_where_the_right_hand_side_allows_it(F, oracle, n
         return f
 
     with F.FluidSolver(n, params={capi.PARAM_TB_MIN_CELLS: 0, capi.PARAM_TB_T16_MIN_CELLS: 0,
-                                  capi.PARAM_TB_MAX_SWEEPS: max_t}) as s:
+                                  capi.PARAM_TB_MAX_SWEEPS: max_t, capi.PARAM_TB_FAST_DIVISION: 1}) as s:
         assert s.division_mode(alpha, beta) == 3 and s.division_mode(1.0, 4.0) == 4
         for b, islands in ((0, 6), (1, 0), (2, 2)):
             x, x0 = field(6), field(islands)
@@ -375,7 +375,7 @@ def test_two_term_division_worst_case_cancellation(F, oracle, n):
         # smooth x0 so that the four neighbours of a cell cancel it too
         x0[...] = x0[n // 2, n // 2]
         x[...] = np.where(rng.random(x.shape) < 0.5, x[n // 2, n // 2], np.nextafter(x[n // 2, n // 2], np.float32(0)))
-        with F.FluidSolver(n, params={capi.PARAM_TB_MIN_CELLS: 0}) as s:
+        with F.FluidSolver(n, params={capi.PARAM_TB_MIN_CELLS: 0, capi.PARAM_TB_FAST_DIVISION: 1}) as s:
             assert s.division_mode(alpha, beta) == 3
             s.upload(u=x, v=x0)
             s.diffuse(0, "u", "v", alpha, beta, 8)

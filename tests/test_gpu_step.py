@@ -84,9 +84,10 @@ def test_step_vs_oracle(F, oracle, n):
             assert_bit_equal(s.download(name), want, "%s n=%d" % (name, n))
 
 
+@pytest.mark.parametrize("fast_div", [2, 1])
 @pytest.mark.parametrize("lane_cols,max_t", [(2, 16), (2, 8), (4, 8), (4, 2)])
 @pytest.mark.parametrize("n", [61, 126, 300])
-def test_steps_through_the_fused_kernel_on_signed_zero_fields(F, oracle, n, lane_cols, max_t):
+def test_steps_through_the_fused_kernel_on_signed_zero_fields(F, oracle, n, lane_cols, max_t, fast_div):
     """Whole steps with the fused Jacobi kernel forced on (it is the default only on large grids), on
     fields drawn from a few dyadic values and both zeros: exact cancellations and -0 are the norm
     there, which is what shows whether the add_source of the zeroed sources (x + dt*0 turns -0 into
@@ -97,7 +98,7 @@ def test_steps_through_the_fused_kernel_on_signed_zero_fields(F, oracle, n, lane
     vals = np.array([-1, -0.5, -0.25, 0.0, -0.0, 0.25, 0.5, 1], np.float32)
     u, v, dens, u0, v0, dens0 = (rng.choice(vals, size=(n + 2, n + 2)).astype(np.float32) for _ in range(6))
     params = {capi.PARAM_TB_MIN_CELLS: 0, capi.PARAM_TB_LANE_COLUMNS: lane_cols, capi.PARAM_TB_MAX_SWEEPS: max_t,
-              capi.PARAM_TB_T16_MIN_CELLS: 0}
+              capi.PARAM_TB_T16_MIN_CELLS: 0, capi.PARAM_TB_FAST_DIVISION: fast_div}
     per_solve = len([t for t in (16, 16, 8) if t <= max_t]) if max_t == 16 else 40 // max_t
     with F.FluidSolver(n, params=params) as s:
         s.upload(u=u, v=v, dens=dens, u_prev=u0, v_prev=v0, dens_prev=dens0)
@@ -121,8 +122,9 @@ def test_steps_through_the_fused_kernel_on_signed_zero_fields(F, oracle, n, lane
         assert_bit_equal(s.download("v_prev"), v0, "vel_step leaves the divergence in v_prev")
 
 
+@pytest.mark.parametrize("fast_div", [2, 1])
 @pytest.mark.parametrize("n", [254, 510])
-def test_decay_through_the_denormal_range_matches_oracle(F, oracle, n):
+def test_decay_through_the_denormal_range_matches_oracle(F, oracle, n, fast_div):
     """With the sources zeroed after step 0 (FluidSequential.c:298-302) every solve restarts from a zero
     first guess and the fields shrink by orders of magnitude per step: within a few steps they hold
     tiny (< 2^-100) and denormal values, and die out entirely after ~20.  Re-inject sources every
@@ -133,7 +135,7 @@ def test_decay_through_the_denormal_range_matches_oracle(F, oracle, n):
     z = np.zeros((n + 2, n + 2), np.float32)
     u, v, dens = z.copy(), z.copy(), z.copy()
     tiny_seen = denormal_seen = 0
-    with F.FluidSolver(n, params={capi.PARAM_TB_MIN_CELLS: 0}) as s:
+    with F.FluidSolver(n, params={capi.PARAM_TB_MIN_CELLS: 0, capi.PARAM_TB_FAST_DIVISION: fast_div}) as s:
         s.upload(u=u, v=v, dens=dens)
         for k in range(3):
             f = initialize_parameters(n, seed=20 + k)

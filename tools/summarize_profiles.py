@@ -1,62 +1,80 @@
 #!/usr/bin/env python3
-"""Turn rocprofv3 output under gpurun_out/prof/ into the summaries committed
-under profiles/:
-  profiles/<tag>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats, verbatim)
-  profiles/<tag>_pmc.json           (per-kernel mean FETCH_SIZE / WRITE_SIZE per
-                                     launch and the corrected HBM bytes)
-gfx950 corrections (MI355X_MICROARCH.md, HBM section): counters are in KiB;
-FETCH_SIZE reports exactly half of a wide coalesced streaming read -- checked
-here on k_add_source, whose read volume is known exactly (2 fields x rows x
-pitch x 4 B) -- so reads are doubled; WRITE_SIZE is exact.
+"""Turn the rocprofv3 output of tools/profile_bench.sh into the summaries committed under profiles/:
+  profiles/<tag>_<grid>_trace_kernel_stats.csv   (rocprofv3 --kernel-trace --stats, verbatim)
+  profiles/<tag>_<grid>_pmc.json                 per kernel: mean FETCH_SIZE / WRITE_SIZE per launch and the corrected
+                                                 HBM bytes; vector instructions per launch (SQ_INSTS_VALU); the clock
+                                                 the chip held (GRBM_GUI_ACTIVE / 8 XCDs / duration); wait shares
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): counters are in KiB; FETCH_SIZE reports exactly half of a wide
+coalesced streaming read (calibrated in round 1 on k_add_source, whose read volume is known exactly), so reads are
+doubled; WRITE_SIZE is exact.
 
-usage: tools/summarize_profiles.py r01 [gpurun_out/prof]
+usage: tools/summarize_profiles.py r02 gpurun_out/prof_4096 [suffix]
 """
 import collections
 import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
 
 def short(name):
-    name = name.replace("void ", "")
-    name = name.split("(")[0].replace("fluid::", "")
-    # k_jacobi_tb<8, 1, float>: the pressure solves (one field per launch); <8, 2, float>: the
-    # batched u/v/density diffusion (three fields per launch) -- kept apart
-    return name
+    return name.replace("void ", "").split("(")[0].replace("fluid::", "")
 
 
 def main():
-    tag = sys.argv[1]
-    root = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof"
+    tag, root = sys.argv[1], sys.argv[2].rstrip("/")
+    grid = re.search(r"prof_(\d+)", os.path.basename(root)).group(1)
+    suffix = ("_" + sys.argv[3]) if len(sys.argv) > 3 else ""
     os.makedirs("profiles", exist_ok=True)
-    for f in glob.glob(os.path.join(root, "trace*", "*", "*_kernel_stats.csv")):
-        sub = os.path.basename(os.path.dirname(os.path.dirname(f)))
-        shutil.copy(f, "profiles/%s_%s_kernel_stats.csv" % (tag, sub))
-        print("kernel stats ->", "profiles/%s_%s_kernel_stats.csv" % (tag, sub))
+    for f in glob.glob(os.path.join(root, "trace", "*_kernel_stats.csv")):
+        dst = "profiles/%s_%s%s_trace_kernel_stats.csv" % (tag, grid, suffix)
+        shutil.copy(f, dst)
+        print("kernel stats ->", dst)
+    if os.path.exists(os.path.join(root, "bench_line.json")):
+        shutil.copy(os.path.join(root, "bench_line.json"), "profiles/%s_%s%s_bench.json" % (tag, grid, suffix))
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
+    dur = collections.defaultdict(dict)
+    for f in glob.glob(os.path.join(root, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            k = short(r["Kernel_Name"])
+            pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                dur[k][r["Dispatch_Id"]] = (float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     out = {}
+    mean = lambda v: sum(v) / len(v)
     for k, c in sorted(pmc.items()):
         if not k.startswith("k_"):
             continue
-        fetch = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) * 1024 if c.get("FETCH_SIZE") else None
-        write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) * 1024 if c.get("WRITE_SIZE") else None
-        out[k] = {"launches_sampled": len(c.get("FETCH_SIZE", c.get("WRITE_SIZE", []))),
-                  "FETCH_SIZE_bytes_raw": fetch, "WRITE_SIZE_bytes": write,
-                  "read_bytes_corrected_x2": None if fetch is None else 2 * fetch,
-                  "hbm_bytes_per_launch": None if fetch is None or write is None else 2 * fetch + write}
+        fetch = mean(c["FETCH_SIZE"]) * 1024 if c.get("FETCH_SIZE") else None
+        write = mean(c["WRITE_SIZE"]) * 1024 if c.get("WRITE_SIZE") else None
+        e = {"launches_sampled": len(c.get("FETCH_SIZE") or c.get("WRITE_SIZE") or c.get("SQ_INSTS_VALU") or []),
+             "FETCH_SIZE_bytes_raw": fetch, "WRITE_SIZE_bytes": write,
+             "read_bytes_corrected_x2": None if fetch is None else 2 * fetch,
+             "hbm_bytes_per_launch": None if fetch is None or write is None else 2 * fetch + write}
+        if c.get("SQ_INSTS_VALU"):
+            e["valu_insts_per_launch"] = mean(c["SQ_INSTS_VALU"])
+            wc = sum(c["SQ_WAVE_CYCLES"]) or 1.0
+            e["wait_any_share"] = sum(c["SQ_WAIT_ANY"]) / wc
+            e["wait_inst_share"] = sum(c["SQ_WAIT_INST_ANY"]) / wc
+            e["active_valu_share"] = sum(c["SQ_ACTIVE_INST_VALU"]) / wc
+        if dur.get(k):
+            g = sum(v[0] for v in dur[k].values())
+            t = sum(v[1] for v in dur[k].values())
+            e["clock_GHz_under_pmc"] = g / 8 / t
+            e["mean_us_under_pmc"] = t / len(dur[k]) / 1e3
+        out[k] = e
     if out:
-        path = "profiles/%s_pmc.json" % tag
+        path = "profiles/%s_%s%s_pmc.json" % (tag, grid, suffix)
         json.dump(out, open(path, "w"), indent=1)
         print("pmc ->", path)
         for k, v in out.items():
-            print("  %-28s read(x2) %8.1f MB  write %8.1f MB" % (
-                k, (v["read_bytes_corrected_x2"] or 0) / 1e6, (v["WRITE_SIZE_bytes"] or 0) / 1e6))
+            print("  %-30s read(x2) %8.1f MB  write %8.1f MB  valu %s  clock %s" % (
+                k, (v["read_bytes_corrected_x2"] or 0) / 1e6, (v["WRITE_SIZE_bytes"] or 0) / 1e6,
+                "%.3g" % v["valu_insts_per_launch"] if v.get("valu_insts_per_launch") else "-",
+                "%.2f GHz" % v["clock_GHz_under_pmc"] if v.get("clock_GHz_under_pmc") else "-"))
 
 
 if __name__ == "__main__":
