@@ -846,7 +846,8 @@ int zero_sources(fluid_ctx* c)
     return FLUID_OK;
 }
 
-int copy_rows(fluid_ctx* c, int field, float* host, const float* chost, int row_lo, int row_hi, bool to_device)
+// `wait` = false only enqueues (fp32 storage): step() / step_src() queue all their fields and wait once
+int copy_rows(fluid_ctx* c, int field, float* host, const float* chost, int row_lo, int row_hi, bool to_device, bool wait = true)
 {
     if (row_lo < 0 || row_hi > c->w || row_lo > row_hi) return fail(FLUID_E_INVALID, "bad row range");
     if (row_lo == row_hi) return FLUID_OK;
@@ -861,7 +862,7 @@ int copy_rows(fluid_ctx* c, int field, float* host, const float* chost, int row_
             HIP_TRY(hipMemcpy2DAsync(dev, dp, chost + (size_t)row_lo * w, hp, hp, rows, hipMemcpyHostToDevice, c->stream));
         else
             HIP_TRY(hipMemcpy2DAsync(host + (size_t)row_lo * w, hp, dev, dp, hp, rows, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (wait) HIP_TRY(hipStreamSynchronize(c->stream));
         return FLUID_OK;
     }
     // fp16 storage: the ABI's host arrays stay float; convert through a host staging buffer
@@ -882,7 +883,14 @@ int copy_rows(fluid_ctx* c, int field, float* host, const float* chost, int row_
     return FLUID_OK;
 }
 
-thread_local fluid_ctx* g_cached = nullptr;
+// the context step() / step_src() keep between calls, one per calling thread; destroyed when the thread ends
+// (for the main thread that is before the HIP runtime's own static destructors run)
+struct CachedCtx {
+    fluid_ctx* c = nullptr;
+    ~CachedCtx();
+};
+thread_local CachedCtx g_cached_holder;
+#define g_cached (g_cached_holder.c)
 
 }  // namespace
 
@@ -1400,6 +1408,10 @@ int fluid_op_diffuse_tol(fluid_ctx* c, int b, int x, int x0, float alpha, float 
 }
 
 // ---- the reference's loop body on host arrays -----------------------------------
+// The host arrays are ordinary pageable memory (the reference malloc()s them, FluidSequential.c:277-282) and travel
+// at PCIe speed as they are: measured 8.7 ms per step() at 4096^2 against 7.1 ms for the same 384 MiB through pinned
+// buffers plus 1.6 ms of compute (tools/step_timing.py).  All copies of a call are enqueued on the context's stream
+// and waited for once.
 int fluid_release_cached(void)
 {
     fluid_ctx* c = g_cached;
@@ -1423,9 +1435,10 @@ int step_src(int N, float dt, float diff, float visc, int iters, float* u, float
     fluid_ctx* c;
     TRY(cached_ctx(N, &c));
     float* host[6] = {u, v, dens, u_prev, v_prev, dens_prev};
-    for (int k = 0; k < 6; ++k) TRY(fluid_upload(c, k, host[k]));
+    for (int k = 0; k < 6; ++k) TRY(copy_rows(c, k, nullptr, host[k], 0, c->w, true, false));
     TRY(fluid_step(c, dt, diff, visc, iters, 1, 1));
-    for (int k = 0; k < 6; ++k) TRY(fluid_download(c, k, host[k]));
+    for (int k = 0; k < 6; ++k) TRY(copy_rows(c, k, host[k], nullptr, 0, c->w, false, false));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return FLUID_OK;
 }
 
@@ -1435,10 +1448,20 @@ int step(int N, float dt, float diff, float visc, float* u, float* v, float* den
     fluid_ctx* c;
     TRY(cached_ctx(N, &c));
     float* host[3] = {u, v, dens};
-    for (int k = 0; k < 3; ++k) TRY(fluid_upload(c, k, host[k]));
+    for (int k = 0; k < 3; ++k) TRY(copy_rows(c, k, nullptr, host[k], 0, c->w, true, false));
     TRY(fluid_step(c, dt, diff, visc, 40, 1, 0));   // 40 sweeps: FluidSequential.c:91
-    for (int k = 0; k < 3; ++k) TRY(fluid_download(c, k, host[k]));
+    for (int k = 0; k < 3; ++k) TRY(copy_rows(c, k, host[k], nullptr, 0, c->w, false, false));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return FLUID_OK;
 }
 
 }  // extern "C"
+
+namespace {
+CachedCtx::~CachedCtx()
+{
+    fluid_ctx* mine = c;
+    c = nullptr;
+    if (mine) (void)fluid_destroy(mine);
+}
+}  // namespace

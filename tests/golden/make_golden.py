@@ -127,6 +127,37 @@ def full_steps(n, iters=40, steps=(1, 2, 5)):
     np.savez_compressed(os.path.join(OUT, "step_n%d_k%d.npz" % (n, iters)), **g)
 
 
+def state_grid(n=14):
+    """The reference's own printStateGrid (FluidSequential.c:32-52) on its state after one step from
+    initializeParameters: stdout of the compiled reference captured at file-descriptor level, plus the three
+    fields it printed.  Pins harness.print_state_grid's text layout."""
+    import ctypes
+    import tempfile
+    build_ref(["%d:40" % n])
+    r = Reference(n, 40)
+    r.lib.printStateGrid.restype, r.lib.printStateGrid.argtypes = None, [np.ctypeslib.ndpointer(np.float32, flags="C")] * 3
+    dens, dens0, u, u0, v, v0 = r.initialize(seed=1)
+    r.step_src(u, v, dens, u0, v0, dens0)
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    with tempfile.TemporaryFile() as tmp:
+        saved = os.dup(1)
+        os.dup2(tmp.fileno(), 1)
+        try:
+            r.lib.printStateGrid(dens, u, v)
+            libc.fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        tmp.seek(0)
+        text = tmp.read().decode()
+    with open(os.path.join(OUT, "state_grid_n%d.txt" % n), "w") as f:
+        f.write(text)
+    np.savez_compressed(os.path.join(OUT, "state_grid_n%d.npz" % n), dens=dens, u=u, v=v)
+    print("printStateGrid: %d bytes captured" % len(text))
+
+
 def checksums():
     """Too big to commit as arrays: CRC-32 of the bytes + float64 sums of step 1 from the
     reference's own initializeParameters (glibc rand, seed 1); FNV-1a too where the
@@ -156,10 +187,14 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["checksums"]:
         checksums()
         sys.exit(0)
+    if sys.argv[1:] == ["state_grid"]:
+        state_grid()
+        sys.exit(0)
     for n in (14, 30, 61):
         operators(n)
     for n in (30, 61, 126):
         full_steps(n)
     full_steps(126, iters=20, steps=(1, 2))
+    state_grid()
     checksums()
     print("golden vectors written to", OUT)

@@ -44,6 +44,37 @@ def test_print_state_grid_layout():
     assert "VELOCITY" in lines and lines[-1] == "[30.000000, 300.000000] [40.000000, 400.000000] "
 
 
+def test_print_state_grid_matches_the_references_own_output():
+    """tests/golden/state_grid_n14.txt is stdout of the compiled reference's printStateGrid
+    (FluidSequential.c:32-52) for the three fields in state_grid_n14.npz (make_golden.py: state_grid)."""
+    import io
+    from conftest import GOLDEN, load_golden
+    from fluidsimulationcuda_amd.harness import print_state_grid
+    g = load_golden("state_grid_n14.npz")
+    buf = io.StringIO()
+    print_state_grid(g["dens"], g["u"], g["v"], out=buf)
+    want = open(os.path.join(GOLDEN, "state_grid_n14.txt")).read()
+    assert buf.getvalue() == want
+    assert "[-0." in want and want.count("\n") == 2 * 16 + 5        # negative velocities, both blocks present
+
+
+@pytest.mark.gpu
+def test_state_dump_of_a_gpu_step_matches_the_references_printout(oracle):
+    """The same text from the GPU: one step from the reference's initializeParameters at N = 14, downloaded and
+    dumped, against what the reference itself printed for that state."""
+    import io
+    import fluidsimulationcuda_amd as F
+    from conftest import GOLDEN
+    from fluidsimulationcuda_amd.harness import print_state_grid
+    dens, dens0, u, u0, v, v0 = oracle.initialize_glibc(14, seed=1)
+    with F.FluidSolver(14) as s:
+        s.upload(u=u, v=v, dens=dens, u_prev=u0, v_prev=v0, dens_prev=dens0)
+        s.step(1, use_sources=True)
+        buf = io.StringIO()
+        print_state_grid(s.download("dens"), s.download("u"), s.download("v"), out=buf)
+    assert buf.getvalue() == open(os.path.join(GOLDEN, "state_grid_n14.txt")).read()
+
+
 def test_threaded_oracle_sweeps_match(oracle):
     rng = np.random.default_rng(8)
     x, x0 = rnd(rng, 97), rnd(rng, 97)
@@ -101,22 +132,38 @@ def test_timing_categories_count_every_operator():
 
 
 @pytest.mark.gpu
-def test_tolerance_terminated_solve_is_opt_in_extension():
+@pytest.mark.parametrize("n,check_every", [(126, 8), (61, 2), (300, 16)])
+def test_tolerance_terminated_solve_is_opt_in_extension(oracle, n, check_every):
+    """fluid_op_diffuse_tol (not the reference's behaviour: it always runs 40 sweeps, FluidSequential.c:91): the field
+    it returns is the oracle's after exactly the sweeps it reports, and the residual it reports is the max-norm
+    residual of that field (float64 evaluation)."""
     import fluidsimulationcuda_amd as F
-    n = 126
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(n)
     x0 = rnd(rng, n)
+    z = np.zeros_like(x0)
     with F.FluidSolver(n) as s:
-        s.upload(v=x0)
-        s.fill("u", 0.0)
+        s.upload(u=z, v=x0)
         a, b = F.coefficients(n, 0.016, 0.0025)
         r0 = s.residual("u", "v", a, b)
-        its, res = s.diffuse_tol(0, "u", "v", a, b, tol=r0 * 1e-4, max_iters=4000, check_every=8)
-        assert 0 < its < 4000 and its % 8 == 0 and res <= r0 * 1e-4
-        # the same number of plain sweeps gives the same field
+        its, res = s.diffuse_tol(0, "u", "v", a, b, tol=r0 * 1e-4, max_iters=4000, check_every=check_every)
+        assert 0 < its < 4000 and its % check_every == 0 and res <= r0 * 1e-4
         got = s.download("u")
-        s.fill("u", 0.0)
-        s.diffuse(0, "u", "v", a, b, its)
-        assert_bit_equal(s.download("u"), got, "diffuse_tol == diffuse(iters done)")
+        want = z.copy()
+        oracle.diffuse(0, want, x0, a, b, its)
+        assert_bit_equal(got, want, "diffuse_tol == oracle.diffuse(%d sweeps)" % its)
+        # its own residual: max |beta*x - alpha*(L+R+U+D) - x0| over the interior, here in float64
+        w = want.astype(np.float64)
+        nb = w[1:-1, :-2] + w[1:-1, 2:] + w[:-2, 1:-1] + w[2:, 1:-1]
+        ref = np.abs(np.float64(np.float32(b)) * w[1:-1, 1:-1] - np.float64(np.float32(a)) * nb - x0[1:-1, 1:-1]).max()
+        assert abs(res - ref) <= 1e-4 * ref + 1e-7 * np.abs(x0).max(), (res, ref)
+        # one block of sweeps earlier the tolerance was not met yet
+        if its > check_every:
+            prev = z.copy()
+            oracle.diffuse(0, prev, x0, a, b, its - check_every)
+            p = prev.astype(np.float64)
+            nbp = p[1:-1, :-2] + p[1:-1, 2:] + p[:-2, 1:-1] + p[2:, 1:-1]
+            assert np.abs(np.float64(np.float32(b)) * p[1:-1, 1:-1] - np.float64(np.float32(a)) * nbp - x0[1:-1, 1:-1]).max() > r0 * 1e-4 * 0.999
         its2, _ = s.diffuse_tol(0, "u", "v", a, b, tol=1e30)
         assert its2 == 0                                   # already converged: no sweeps
+        its3, res3 = s.diffuse_tol(0, "u", "v", a, b, tol=0.0, max_iters=10, check_every=4)
+        assert its3 == 10 and res3 > 0.0                   # the cap: blocks of check_every, the last one shortened to an even rest
