@@ -273,7 +273,8 @@ def main():
     def rates(elapsed, jac_ms, prs_ms, t, steps, cells_):
         t_sweep = jac_ms * 1e-3 / max(t["sweeps"], 1)
         t_psweep = prs_ms * 1e-3 / max(t["pressure_sweeps"], 1)
-        return {"value": cells_ / t_psweep / 1e6, "ms_per_step": elapsed * 1e3 / steps,
+        cats = {k: t[k + "_ms"] / steps for k in ("source", "diffusion", "divergence", "projection", "advection")}
+        return {"value": cells_ / t_psweep / 1e6, "ms_per_step": elapsed * 1e3 / steps, "kernel_ms_per_step": cats,
                 "us_per_jacobi_sweep": t_psweep * 1e6, "all_solves_value": cells_ / t_sweep / 1e6,
                 "all_solves_us_per_jacobi_sweep": t_sweep * 1e6, "t_sweep": t_sweep}
 
@@ -328,6 +329,9 @@ def main():
                        world, ("RCCL, library-native exchange" if exchange == "rccl" else "RCCL via torch.distributed")
                        if a.backend == "nccl" else a.backend + " (host-staged rehearsal)")},
         "ms_per_sim_step": ms_step,
+        "kernel_ms_per_step": dict(r["kernel_ms_per_step"], note="HIP events per operator category (the reference's timers, "
+                                   "FluidSequential.c:192-234); 'projection' holds the gradient subtractions, the second "
+                                   "one fused with the density advection"),
         "us_per_jacobi_sweep": r["us_per_jacobi_sweep"],
         "all_solves": {"value": r["all_solves_value"], "unit": "Mcells/s", "us_per_jacobi_sweep": t_sweep * 1e6,
                        "note": "the same rate over all 200 sweeps of the step (3 diffusions, whose exact division "
@@ -385,7 +389,7 @@ def main():
         line["value_ordinary_data"] = {
             "value": r2["value"], "unit": "Mcells/s", "us_per_jacobi_sweep": r2["us_per_jacobi_sweep"],
             "all_solves_value": r2["all_solves_value"], "all_solves_us_per_jacobi_sweep": r2["all_solves_us_per_jacobi_sweep"],
-            "ms_per_step": r2["ms_per_step"], "source_copies_ms_per_step": copy_ms,
+            "ms_per_step": r2["ms_per_step"], "source_copies_ms_per_step": copy_ms, "kernel_ms_per_step": r2["kernel_ms_per_step"],
             "frac_compulsory": bpc * cells * t2["jacobi_field_launches"] / (j2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "note": "same grid and kernels; the three source fields are re-injected before every step (device-to-device "
                     "copies, included in ms_per_step, %.3f ms of it) and consumed by add_source, so all fields keep "

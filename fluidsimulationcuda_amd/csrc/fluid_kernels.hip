@@ -959,102 +959,152 @@ __global__ __launch_bounds__(256) void k_tile_min_abs(TileBatch tb, int pitch, i
 // a5  advect (FluidSequential.c:107-141): the velocity streams in coalesced, the
 // four bilinear taps of d0 per cell are gathered (served by L2 / Infinity Cache).
 // ---------------------------------------------------------------------------
-// Each thread takes four consecutive cells of a row: the velocity comes in and the result goes out as
-// one 16-byte access per field (4-byte accesses left these kernels at half the bandwidth of the other
-// streaming kernels), and the four back-traces give the memory system 16 or 32 independent taps per
-// thread to work on.  Per cell the arithmetic is the reference's, in its order.
+// What bounds these kernels is the gather, not HBM: a wave-wide load whose lanes are 16 bytes apart touches eight
+// 128-byte lines to use a quarter of each, and a cell needs four taps per advected field.  So a wave works on 256
+// consecutive cells of a row in four rounds of 64 -- lane l takes cells l, 64+l, 128+l, 192+l -- which makes every
+// access of every round lane-contiguous: velocities in and results out as one dword per lane (256 bytes per wave
+// instruction, whole lines), and the two horizontally adjacent taps of a cell as ONE 8-byte load (they are contiguous
+// in memory; 4-byte aligned, which global loads allow), so a round's taps touch three lines per instruction, not
+// eight.  Four independent back-traces per thread keep 8 or 16 loads in flight.  Per cell the arithmetic is the
+// reference's, in its order.
+// Offsets are BYTE offsets of type IDX: unsigned for fields below 2^32 bytes (every size up to ~32700^2 fp32), so an
+// access is a scalar base plus a 32-bit vector offset and no 64-bit vector arithmetic is spent on addresses; size_t beyond.
+template <typename S, typename IDX>
+__device__ __forceinline__ const S* at(const S* base, IDX byte_off) { return reinterpret_cast<const S*>(reinterpret_cast<const char*>(base) + byte_off); }
+template <typename S, typename IDX>
+__device__ __forceinline__ S* at(S* base, IDX byte_off) { return reinterpret_cast<S*>(reinterpret_cast<char*>(base) + byte_off); }
+
+template <typename IDX>
 struct AdvectTap {
-    size_t o;             // offset of the top-left tap
+    IDX o;                // byte offset of the top-left tap
     float s0, s1, t0, t1;
 };
 
-__device__ __forceinline__ AdvectTap advect_trace(int j, int i, float uu, float vv, float dt0, int n, size_t P)
+// P: row pitch in bytes, E: element size in bytes
+template <typename IDX>
+__device__ __forceinline__ AdvectTap<IDX> advect_trace(int j, int i, float uu, float vv, float dt0, int n, IDX P, IDX E)
 {
     float px = (float)j - dt0 * uu;
     float py = (float)i - dt0 * vv;
     const float hi = (float)n + 0.5f;
-    if (px < 0.5f) px = 0.5f;
-    if (px > hi) px = hi;
-    if (py < 0.5f) py = 0.5f;
-    if (py > hi) py = hi;
+    // FluidSequential.c:117-127: if (x < 0.5) x = 0.5; if (x > N + 0.5) x = N + 0.5 -- as max / min (the same value
+    // for every x that is not NaN; a NaN velocity, which sends the reference's (int) cast into undefined behaviour,
+    // lands on the lower bound here)
+    px = __builtin_fminf(__builtin_fmaxf(px, 0.5f), hi);
+    py = __builtin_fminf(__builtin_fmaxf(py, 0.5f), hi);
     const int j0 = (int)px, i0 = (int)py;
-    AdvectTap t;
+    AdvectTap<IDX> t;
     t.s1 = px - (float)j0;
     t.s0 = 1.0f - t.s1;
     t.t1 = py - (float)i0;
     t.t0 = 1.0f - t.t1;
-    t.o = (size_t)i0 * P + XOFF + j0;
+    t.o = (IDX)i0 * P + (IDX)(XOFF + j0) * E;
     return t;
 }
 
-template <typename S>
-__device__ __forceinline__ float advect_sample(const S* __restrict__ d0, size_t P, const AdvectTap& t)
+// two horizontally adjacent cells in one access
+struct __attribute__((packed, aligned(4))) FloatPair { float a, b; };
+__device__ __forceinline__ void ld_pair(const float* p, float& a, float& b)
 {
-    const S* q = d0 + t.o;
-    const float a = t.t0 * ld1(q) + t.t1 * ld1(q + P);
-    const float e = t.t0 * ld1(q + 1) + t.t1 * ld1(q + P + 1);
+    const FloatPair v = *reinterpret_cast<const FloatPair*>(p);
+    a = v.a;
+    b = v.b;
+}
+__device__ __forceinline__ void ld_pair(const half_t* p, float& a, float& b)
+{
+    a = ld1(p);
+    b = ld1(p + 1);
+}
+
+template <typename S, typename IDX>
+__device__ __forceinline__ float advect_sample(const S* __restrict__ d0, IDX P, const AdvectTap<IDX>& t)
+{
+    float q00, q10, q01, q11;            // q[col][row]
+    ld_pair(at(d0, t.o), q00, q10);
+    ld_pair(at(d0, t.o + P), q01, q11);
+    const float a = t.t0 * q00 + t.t1 * q01;
+    const float e = t.t0 * q10 + t.t1 * q11;
     return t.s0 * a + t.s1 * e;
 }
 
-// store four results starting at column j (16-byte aligned), the ragged end of a row cell by cell
-template <typename S>
-__device__ __forceinline__ void advect_store(S* __restrict__ d, size_t P, int n, int b, int j, int i, const float (&val)[4])
-{
-    S* row = d + (size_t)i * P + XOFF + j;
-    if (j + 3 <= n) {
-        st4(row, make_float4(val[0], val[1], val[2], val[3]));
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (j + k <= n) st1(row + k, val[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (j + k <= n) emit_ghosts(d, P, n, b, j + k, i, val[k]);
-}
+constexpr int kAdvectRounds = 4;         // cells per thread, 64 apart
+// first column of a thread's round-0 cell: a block covers 256 threads x 4 rounds = 1024 consecutive columns
+__device__ __forceinline__ int advect_col0() { return 1 + (int)blockIdx.x * 1024 + (int)(threadIdx.x >> 6) * 256 + (int)(threadIdx.x & 63); }
+// does this block hold a cell next to a wall (wave-uniform)?  Only those run the ghost-cell code at all.
+__device__ __forceinline__ bool advect_wall_block(int i, int n) { return i == 1 || i == n || blockIdx.x == 0 || blockIdx.x == gridDim.x - 1; }
 
-template <typename S>
+// (A block that walks eight rows and loads the next row's velocity ahead of the current row's taps was measured slower:
+// 324 against 294 us at 8192^2.  The texture addresser is busy 94 % of k_advect2's time -- rocprofv3 TA_BUSY_avr --
+// so what these kernels wait for is the address path of their gathers, neither HBM nor latency.)
+template <typename S, typename IDX>
 __global__ __launch_bounds__(256) void k_advect(S* __restrict__ d, const S* __restrict__ d0, const S* __restrict__ u,
                                                 const S* __restrict__ v, int pitch, int n, int row_lo, int row_hi,
                                                 float dt0, int b)
 {
-    const int j = 1 + 4 * (blockIdx.x * 256 + threadIdx.x);
+    const int j0 = advect_col0();
     const int i = row_lo + blockIdx.y;
-    if (j > n || i >= row_hi) return;
-    const size_t P = (size_t)pitch;
-    const size_t c = (size_t)i * P + XOFF + j;
-    const float4 u4 = ld4(u + c), v4 = ld4(v + c);       // columns past n read pad / ghost floats: unused
-    const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
-    float val[4];
+    if (i >= row_hi) return;
+    const IDX E = (IDX)sizeof(S), P = (IDX)pitch * E;
+    const IDX r = (IDX)i * P + (IDX)XOFF * E;
+    const bool wall = advect_wall_block(i, n);
+    float uu[kAdvectRounds], vv[kAdvectRounds], val[kAdvectRounds];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) val[k] = advect_sample(d0, P, advect_trace(j + k, i, uu[k], vv[k], dt0, n, P));
-    advect_store(d, P, n, b, j, i, val);
+    for (int k = 0; k < kAdvectRounds; ++k) {
+        const IDX c = r + (IDX)min(j0 + 64 * k, n) * E;  // lanes past the row's end repeat its last cell (and store nothing)
+        uu[k] = ld1(at(u, c));
+        vv[k] = ld1(at(v, c));
+    }
+#pragma unroll
+    for (int k = 0; k < kAdvectRounds; ++k) val[k] = advect_sample(d0, P, advect_trace<IDX>(min(j0 + 64 * k, n), i, uu[k], vv[k], dt0, n, P, E));
+#pragma unroll
+    for (int k = 0; k < kAdvectRounds; ++k) {
+        const int j = j0 + 64 * k;
+        if (j <= n) {
+            st1(at(d, r + (IDX)j * E), val[k]);
+            if (wall) emit_ghosts(d, (size_t)pitch, n, b, j, i, val[k]);
+        }
+    }
 }
 
 // Two advections along the same velocity field in one pass (vel_step advects u and v, both along
 // (u0, v0), FluidSequential.c:213-214): the velocity is read and the back-trace computed once, and
 // the eight taps of the two sources sit at the same offsets.
-template <typename S>
+template <typename S, typename IDX>
 __global__ __launch_bounds__(256) void k_advect2(S* __restrict__ da, const S* __restrict__ d0a, int ba, S* __restrict__ db,
                                                  const S* __restrict__ d0b, int bb, const S* __restrict__ u,
                                                  const S* __restrict__ v, int pitch, int n, int row_lo, int row_hi, float dt0)
 {
-    const int j = 1 + 4 * (blockIdx.x * 256 + threadIdx.x);
+    const int j0 = advect_col0();
     const int i = row_lo + blockIdx.y;
-    if (j > n || i >= row_hi) return;
-    const size_t P = (size_t)pitch;
-    const size_t c = (size_t)i * P + XOFF + j;
-    const float4 u4 = ld4(u + c), v4 = ld4(v + c);
-    const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
-    float va[4], vb[4];
+    if (i >= row_hi) return;
+    const IDX E = (IDX)sizeof(S), P = (IDX)pitch * E;
+    const IDX r = (IDX)i * P + (IDX)XOFF * E;
+    const bool wall = advect_wall_block(i, n);
+    float uu[kAdvectRounds], vv[kAdvectRounds], va[kAdvectRounds], vb[kAdvectRounds];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const AdvectTap t = advect_trace(j + k, i, uu[k], vv[k], dt0, n, P);
+    for (int k = 0; k < kAdvectRounds; ++k) {
+        const IDX c = r + (IDX)min(j0 + 64 * k, n) * E;
+        uu[k] = ld1(at(u, c));
+        vv[k] = ld1(at(v, c));
+    }
+#pragma unroll
+    for (int k = 0; k < kAdvectRounds; ++k) {
+        const AdvectTap<IDX> t = advect_trace<IDX>(min(j0 + 64 * k, n), i, uu[k], vv[k], dt0, n, P, E);
         va[k] = advect_sample(d0a, P, t);
         vb[k] = advect_sample(d0b, P, t);
     }
-    advect_store(da, P, n, ba, j, i, va);
-    advect_store(db, P, n, bb, j, i, vb);
+#pragma unroll
+    for (int k = 0; k < kAdvectRounds; ++k) {
+        const int j = j0 + 64 * k;
+        if (j <= n) {
+            st1(at(da, r + (IDX)j * E), va[k]);
+            st1(at(db, r + (IDX)j * E), vb[k]);
+            if (wall) {
+                emit_ghosts(da, (size_t)pitch, n, ba, j, i, va[k]);
+                emit_ghosts(db, (size_t)pitch, n, bb, j, i, vb[k]);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1112,7 +1162,7 @@ __global__ __launch_bounds__(256) void k_subtract_gradient(S* __restrict__ u, S*
 // of the second projection, then the density advection along the velocity it has just produced.  The
 // back-trace of cell (i, j) needs u and v at (i, j) only -- the values this thread holds in registers
 // (as stored: rounded to the storage type first) -- so the advection need not read the two fields back.
-// Four cells per thread, per cell the arithmetic of k_subtract_gradient and k_advect.
+// Four cells per thread (64 apart, as in k_advect), per cell the arithmetic of k_subtract_gradient and k_advect.
 template <typename S>
 __device__ __forceinline__ float as_stored(float v)
 {
@@ -1120,34 +1170,49 @@ __device__ __forceinline__ float as_stored(float v)
     else return v;
 }
 
-template <typename S>
+template <typename S, typename IDX>
 __global__ __launch_bounds__(256) void k_gradient_advect(S* __restrict__ u, S* __restrict__ v, const S* __restrict__ p,
                                                          S* __restrict__ d, const S* __restrict__ d0, int pitch, int n,
                                                          int row_lo, int row_hi, float h, float dt0, int b)
 {
-    const int j = 1 + 4 * (blockIdx.x * 256 + threadIdx.x);
+    const int j0 = advect_col0();
     const int i = row_lo + blockIdx.y;
-    if (j > n || i >= row_hi) return;
-    const size_t P = (size_t)pitch;
-    const size_t c = (size_t)i * P + XOFF + j;
-    const float4 pm = ld4(p + c), pu = ld4(p + c - P), pd = ld4(p + c + P), u4 = ld4(u + c), v4 = ld4(v + c);
-    const float pw[6] = {ld1(p + c - 1), pm.x, pm.y, pm.z, pm.w, ld1(p + c + 4)};     // columns j-1 .. j+4 of row i
-    const float up[4] = {pu.x, pu.y, pu.z, pu.w}, dn[4] = {pd.x, pd.y, pd.z, pd.w};
-    const float uo[4] = {u4.x, u4.y, u4.z, u4.w}, vo[4] = {v4.x, v4.y, v4.z, v4.w};
-    float nu[4], nv[4], val[4];
+    if (i >= row_hi) return;
+    const IDX E = (IDX)sizeof(S), P = (IDX)pitch * E;
+    const IDX r = (IDX)i * P + (IDX)XOFF * E;
+    const bool wall = advect_wall_block(i, n);
+    float nu[kAdvectRounds], nv[kAdvectRounds], val[kAdvectRounds];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float gx = 0.5f * (pw[k + 2] - pw[k]);
-        const float gy = 0.5f * (dn[k] - up[k]);
-        nu[k] = uo[k] - gx / h;
-        nv[k] = vo[k] - gy / h;
+    for (int k = 0; k < kAdvectRounds; ++k) {            // lane-contiguous dwords; the row's left/right neighbours are L1 hits
+        const IDX c = r + (IDX)min(j0 + 64 * k, n) * E;
+        const float gx = 0.5f * (ld1(at(p, c + E)) - ld1(at(p, c - E)));
+        const float gy = 0.5f * (ld1(at(p, c + P)) - ld1(at(p, c - P)));
+        nu[k] = ld1(at(u, c)) - gx / h;
+        nv[k] = ld1(at(v, c)) - gy / h;
     }
-    advect_store(u, P, n, 1, j, i, nu);
-    advect_store(v, P, n, 2, j, i, nv);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        val[k] = advect_sample(d0, P, advect_trace(j + k, i, as_stored<S>(nu[k]), as_stored<S>(nv[k]), dt0, n, P));
-    advect_store(d, P, n, b, j, i, val);
+    for (int k = 0; k < kAdvectRounds; ++k) {
+        const int j = j0 + 64 * k;
+        if (j <= n) {
+            st1(at(u, r + (IDX)j * E), nu[k]);
+            st1(at(v, r + (IDX)j * E), nv[k]);
+            if (wall) {
+                emit_ghosts(u, (size_t)pitch, n, 1, j, i, nu[k]);
+                emit_ghosts(v, (size_t)pitch, n, 2, j, i, nv[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kAdvectRounds; ++k)
+        val[k] = advect_sample(d0, P, advect_trace<IDX>(min(j0 + 64 * k, n), i, as_stored<S>(nu[k]), as_stored<S>(nv[k]), dt0, n, P, E));
+#pragma unroll
+    for (int k = 0; k < kAdvectRounds; ++k) {
+        const int j = j0 + 64 * k;
+        if (j <= n) {
+            st1(at(d, r + (IDX)j * E), val[k]);
+            if (wall) emit_ghosts(d, (size_t)pitch, n, b, j, i, val[k]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1223,6 +1288,8 @@ __global__ __launch_bounds__(256) void k_residual(const S* __restrict__ x, const
 // `st` selects the field storage type the untyped pointers refer to.
 // ---------------------------------------------------------------------------
 static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
+// element offsets into a field fit 32 bits (with a byte offset below 2^32 for the hardware's address add)
+static inline bool narrow_index(int st, int pitch, int n) { return (size_t)(n + 2) * (size_t)pitch * storage_bytes(st) < (1ull << 32); }
 
 #define FLUID_BY_STORAGE(st, CALL)            \
     do {                                      \
@@ -1351,17 +1418,26 @@ void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u
                    int row_lo, int row_hi, float dt0, int b)
 {
     if (row_hi <= row_lo) return;
-    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_advect<S>, dim3(cdiv(cdiv(n, 4), 256), row_hi - row_lo), dim3(256), 0, s, (S*)d,
-                                            (const S*)d0, (const S*)u, (const S*)v, pitch, n, row_lo, row_hi, dt0, b));
+    const dim3 grid(cdiv(n, 1024), row_hi - row_lo);
+    if (narrow_index(st, pitch, n))
+        FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_advect<S, unsigned>), grid, dim3(256), 0, s, (S*)d, (const S*)d0, (const S*)u,
+                                                (const S*)v, pitch, n, row_lo, row_hi, dt0, b));
+    else
+        FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_advect<S, size_t>), grid, dim3(256), 0, s, (S*)d, (const S*)d0, (const S*)u,
+                                                (const S*)v, pitch, n, row_lo, row_hi, dt0, b));
 }
 
 void launch_advect2(hipStream_t s, int st, void* da, const void* d0a, int ba, void* db, const void* d0b, int bb, const void* u,
                     const void* v, int pitch, int n, int row_lo, int row_hi, float dt0)
 {
     if (row_hi <= row_lo) return;
-    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_advect2<S>, dim3(cdiv(cdiv(n, 4), 256), row_hi - row_lo), dim3(256), 0, s, (S*)da,
-                                            (const S*)d0a, ba, (S*)db, (const S*)d0b, bb, (const S*)u, (const S*)v, pitch, n,
-                                            row_lo, row_hi, dt0));
+    const dim3 grid(cdiv(n, 1024), row_hi - row_lo);
+    if (narrow_index(st, pitch, n))
+        FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_advect2<S, unsigned>), grid, dim3(256), 0, s, (S*)da, (const S*)d0a, ba, (S*)db,
+                                                (const S*)d0b, bb, (const S*)u, (const S*)v, pitch, n, row_lo, row_hi, dt0));
+    else
+        FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_advect2<S, size_t>), grid, dim3(256), 0, s, (S*)da, (const S*)d0a, ba, (S*)db,
+                                                (const S*)d0b, bb, (const S*)u, (const S*)v, pitch, n, row_lo, row_hi, dt0));
 }
 
 void launch_divergence(hipStream_t s, int st, const void* u, const void* v, void* p, void* div, int pitch, int n,
@@ -1385,8 +1461,13 @@ void launch_gradient_advect(hipStream_t s, int st, void* u, void* v, const void*
                             int row_lo, int row_hi, float h, float dt0, int b)
 {
     if (row_hi <= row_lo) return;
-    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_gradient_advect<S>, dim3(cdiv(cdiv(n, 4), 256), row_hi - row_lo), dim3(256), 0, s,
-                                            (S*)u, (S*)v, (const S*)p, (S*)d, (const S*)d0, pitch, n, row_lo, row_hi, h, dt0, b));
+    const dim3 grid(cdiv(n, 1024), row_hi - row_lo);
+    if (narrow_index(st, pitch, n))
+        FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_gradient_advect<S, unsigned>), grid, dim3(256), 0, s, (S*)u, (S*)v, (const S*)p,
+                                                (S*)d, (const S*)d0, pitch, n, row_lo, row_hi, h, dt0, b));
+    else
+        FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_gradient_advect<S, size_t>), grid, dim3(256), 0, s, (S*)u, (S*)v, (const S*)p,
+                                                (S*)d, (const S*)d0, pitch, n, row_lo, row_hi, h, dt0, b));
 }
 
 void launch_absmax2(hipStream_t s, int st, const void* u, const void* v, int pitch, int n, int row_lo, int row_hi,
