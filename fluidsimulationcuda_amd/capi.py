@@ -18,6 +18,7 @@ STORAGE_F32, STORAGE_F16 = 0, 1
 PARAM_TB_MAX_SWEEPS, PARAM_TB_ROWS, PARAM_HALO, PARAM_TB_FAST_DIVISION, PARAM_TB_MIN_CELLS, PARAM_TB_EDGE_ROWS_PCT = 0, 1, 2, 3, 4, 5
 PARAM_TB_LANE_COLUMNS = 6
 PARAM_TB_T16_MIN_CELLS = 7
+PARAM_TB_AUTOTUNE = 8
 XCHG_HALO, XCHG_GATHER, XCHG_MAX, XCHG_MAX_BEGIN, XCHG_MAX_END = 0, 1, 2, 3, 4
 RCCL_ID_BYTES = 128
 FIELD_NAMES = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev", "tmp0", "tmp1", "tmp2")
@@ -87,6 +88,7 @@ SIGNATURES = {
     "fluid_absmax_velocity": [_ctx, _i, _i, C.POINTER(_f)],
     "fluid_set_jacobi_variant": [_ctx, _i],
     "fluid_division_mode": [_ctx, _f, _f, C.POINTER(_i)],
+    "fluid_autotune_pending": [_ctx, C.POINTER(_i)],
     "fluid_set_param": [_ctx, _i, _i],
     "fluid_timing_enable": [_ctx, _i],
     "fluid_timing_read": [_ctx, C.POINTER(Timing), _i],

@@ -352,6 +352,136 @@ int op_add_source(fluid_ctx* c, int x, int s, float dt)
     return FLUID_OK;
 }
 
+// ---- strip-height tuner -----------------------------------------------------------------------------------
+// The fused Jacobi kernel's speed depends on the strip height `rb` in ways no closed form captured (how the
+// (window, strip) blocks fall into rounds on the 256 CUs and 8 XCDs, how much pipeline fill they repeat): over a sweep
+// of heights the closed-form pick was 10-23 % off the best on most shapes (tools/slab_rb_sweep.py).  Results do not
+// depend on rb, so the library measures instead: for each launch shape -- sweeps per launch, fields per launch, form,
+// rows, N, lane width, storage -- the first launches cycle through a handful of heights with an event pair around
+// each, and once every candidate has two samples the fastest is kept.  The table is shared by all contexts of the
+// process (a benchmark can tune in a throw-away context); harvesting is by hipEventQuery, never a wait.
+struct RbTuner {
+    struct Entry {
+        std::vector<int> cand;
+        std::vector<float> best_ms;
+        std::vector<int> samples, issued;
+        int fixed = 0;
+    };
+    std::mutex mu;
+    std::unordered_map<unsigned long long, Entry> table;
+};
+RbTuner& rb_tuner()
+{
+    static RbTuner t;
+    return t;
+}
+constexpr int kTuneSamples = 2;
+
+unsigned long long tune_key(const fluid_ctx* c, int T, int m, bool mode4, long long rows_n)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    unsigned long long h = 1469598103934665603ull;
+    for (unsigned long long v : {(unsigned long long)dev, (unsigned long long)c->n, (unsigned long long)rows_n, (unsigned long long)T,
+                                 (unsigned long long)m, (unsigned long long)mode4, (unsigned long long)c->tb_nv, (unsigned long long)c->st,
+                                 (unsigned long long)c->tb_edge_pct}) {
+        h ^= v;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+// finished trials -> the table (never waits)
+void tune_harvest(fluid_ctx* c)
+{
+    if (c->trials.empty()) return;
+    RbTuner& t = rb_tuner();
+    std::lock_guard<std::mutex> lock(t.mu);
+    size_t keep = 0;
+    for (size_t k = 0; k < c->trials.size(); ++k) {
+        fluid_ctx::Trial& tr = c->trials[k];
+        if (hipEventQuery(tr.b) != hipSuccess) {
+            c->trials[keep++] = tr;
+            continue;
+        }
+        float ms = 0.f;
+        auto it = t.table.find(tr.key);
+        if (hipEventElapsedTime(&ms, tr.a, tr.b) == hipSuccess && it != t.table.end() && !it->second.fixed) {
+            RbTuner::Entry& e = it->second;
+            e.best_ms[tr.cand] = e.samples[tr.cand] ? std::min(e.best_ms[tr.cand], ms) : ms;
+            e.samples[tr.cand] += 1;
+            bool done = true;
+            for (int sdone : e.samples) done = done && sdone >= kTuneSamples;
+            if (done) {
+                e.fixed = e.cand[std::min_element(e.best_ms.begin(), e.best_ms.end()) - e.best_ms.begin()];
+                if (std::getenv("FLUID_TUNE_LOG")) {
+                    std::string msg;
+                    for (size_t q = 0; q < e.cand.size(); ++q) msg += " " + std::to_string(e.cand[q]) + ":" + std::to_string((int)(e.best_ms[q] * 1e3f));
+                    fprintf(stderr, "[fluid tune] key %016llx -> %d rows  (height:us%s)\n", tr.key, e.fixed, msg.c_str());
+                }
+            }
+        }
+        c->free_events.push_back(tr.a);
+        c->free_events.push_back(tr.b);
+    }
+    c->trials.resize(keep);
+}
+
+// the height to use for this launch; *trial >= 0: it is a measurement of candidate *trial (tune_begin / tune_end bracket the launch)
+int tune_pick(fluid_ctx* c, unsigned long long key, int heuristic, int T, long long rows_n, int* trial)
+{
+    *trial = -1;
+    tune_harvest(c);
+    RbTuner& t = rb_tuner();
+    std::lock_guard<std::mutex> lock(t.mu);
+    RbTuner::Entry& e = t.table[key];
+    if (e.fixed) return e.fixed;
+    if (e.cand.empty()) {
+        e.cand.push_back(heuristic);
+        for (int r : {48, 56, 64, 80, 96, 112, 128, 160, 192}) {
+            if (r < 2 * T || r >= rows_n + 2 * T) continue;     // (a height past the rows is one strip: the tallest candidate covers it)
+            if (std::find(e.cand.begin(), e.cand.end(), r) == e.cand.end()) e.cand.push_back(r);
+        }
+        if (e.cand.size() == 1) {                                // nothing to choose from (tiny grids)
+            e.fixed = heuristic;
+            return heuristic;
+        }
+        e.best_ms.assign(e.cand.size(), 0.f);
+        e.samples.assign(e.cand.size(), 0);
+        e.issued.assign(e.cand.size(), 0);
+    }
+    // the candidate with the fewest trials issued so far (finished or still in flight)
+    const int pick = (int)(std::min_element(e.issued.begin(), e.issued.end()) - e.issued.begin());
+    if (e.issued[pick] >= kTuneSamples + 2) return e.cand[0];   // all issued, results still in flight: the closed-form pick meanwhile
+    e.issued[pick] += 1;
+    *trial = pick;
+    return e.cand[pick];
+}
+
+int tune_begin(fluid_ctx* c, unsigned long long key, int trial)
+{
+    fluid_ctx::Trial tr{};
+    tr.key = key;
+    tr.cand = trial;
+    for (hipEvent_t* ev : {&tr.a, &tr.b}) {
+        if (!c->free_events.empty()) {
+            *ev = c->free_events.back();
+            c->free_events.pop_back();
+        } else {
+            HIP_TRY(hipEventCreate(ev));
+        }
+    }
+    HIP_TRY(hipEventRecord(tr.a, c->stream));
+    c->trials.push_back(tr);
+    return FLUID_OK;
+}
+
+int tune_end(fluid_ctx* c)
+{
+    HIP_TRY(hipEventRecord(c->trials.back().b, c->stream));
+    return FLUID_OK;
+}
+
 // Sweeps fused into the next launch of a solve that has `room` sweeps it can still run (remaining sweeps,
 // and on slabs the valid reach).  Greedy: the deepest launch that fits.
 int pick_sweeps(const fluid_ctx* c, int room, bool canonical, bool small, long long slab_cells, bool all_mode4)
@@ -540,9 +670,18 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                     rb = 2 * T;
                     while (rb < cap && blocks(rb) > room) rb += 2;
                 }
+                // ... and that closed form is only the first candidate of the run-time tuner (see RbTuner)
+                int trial = -1;
+                unsigned long long key = 0;
+                if (c->tb_rows <= 0 && c->autotune) {
+                    key = tune_key(c, T, m, divmode[first] == 4, hi - lo);
+                    rb = tune_pick(c, key, rb, T, hi - lo, &trial);
+                }
                 // edge windows (ghost columns) cost ~1.6x per row: shorter strips there keep the launch balanced
                 const int rb_edge = std::min(rb, edge_rows(rb));
+                if (trial >= 0) TRY(tune_begin(c, key, trial));
                 fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], c->tb_nv, bt, c->pitch, c->n, lo, hi, rb, rb_edge);
+                if (trial >= 0) TRY(tune_end(c));
                 if (c->timing) {
                     c->launches += 1;
                     c->field_launches += m;
@@ -1035,6 +1174,17 @@ int fluid_destroy(fluid_ctx* c)
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
     }
+    if (!c->trials.empty()) {                    // measurements that die with the context are handed back to the tuner
+        RbTuner& t = rb_tuner();
+        std::lock_guard<std::mutex> lock(t.mu);
+        for (auto& tr : c->trials) {
+            auto it = t.table.find(tr.key);
+            if (it != t.table.end() && !it->second.fixed && it->second.issued[tr.cand] > 0) it->second.issued[tr.cand] -= 1;
+            (void)hipEventDestroy(tr.a);
+            (void)hipEventDestroy(tr.b);
+        }
+    }
+    for (hipEvent_t ev : c->free_events) (void)hipEventDestroy(ev);
     fluid_detail::rccl_release(c->rccl);
     c->rccl = nullptr;
     if (c->h_scalar) (void)hipHostFree(c->h_scalar);
@@ -1157,6 +1307,9 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
         if (value < 0 || value > 2) return fail(FLUID_E_INVALID, "TB_FAST_DIVISION must be 0, 1 or 2");
         c->fast_div = value;
         return FLUID_OK;
+    case FLUID_PARAM_TB_AUTOTUNE:
+        c->autotune = value != 0;
+        return FLUID_OK;
     case FLUID_PARAM_TB_T16_MIN_CELLS:
         if (value < -1) return fail(FLUID_E_INVALID, "TB_T16_MIN_CELLS must be >= 0, or -1 for the default rule");
         c->tb_t16_min_cells = value;
@@ -1172,6 +1325,19 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
     default:
         return fail(FLUID_E_INVALID, "unknown parameter %d", key);
     }
+}
+
+int fluid_autotune_pending(fluid_ctx* c, int* shapes_open)
+{
+    TRY(check_ctx(c));
+    if (!shapes_open) return fail(FLUID_E_INVALID, "null pointer");
+    tune_harvest(c);
+    RbTuner& t = rb_tuner();
+    std::lock_guard<std::mutex> lock(t.mu);
+    int open = 0;
+    for (auto& kv : t.table) open += kv.second.fixed ? 0 : 1;
+    *shapes_open = open;
+    return FLUID_OK;
 }
 
 int fluid_division_mode(fluid_ctx* c, float alpha, float beta, int* mode)

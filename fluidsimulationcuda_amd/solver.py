@@ -156,6 +156,12 @@ class FluidSolver:
         capi.check(capi.lib().fluid_division_mode(self._h, alpha, beta, C.byref(m)))
         return m.value
 
+    def autotune_pending(self):
+        """Launch shapes whose strip height the run-time tuner is still measuring (process-wide)."""
+        m = C.c_int()
+        capi.check(capi.lib().fluid_autotune_pending(self._h, C.byref(m)))
+        return m.value
+
     def set_param(self, key, value):
         capi.check(capi.lib().fluid_set_param(self._h, key, value))
 

@@ -69,6 +69,9 @@ enum {
     ,FLUID_PARAM_TB_T16_MIN_CELLS = 7 /* 16-sweep launches (fp32 storage, 2-column lanes) on slabs of at least this many
                                       cells, for either form of the solve; -1 (default): the measured rule -- from
                                       8 M cells, the general form only once a field outgrows 96 MiB     */
+    ,FLUID_PARAM_TB_AUTOTUNE = 8   /* 1 (default): with TB_ROWS = 0 the strip height of each launch shape is measured
+                                      at run time -- the first ~20 launches of a shape try a handful of heights, the
+                                      fastest is kept for the process; 0: the closed-form choice.  Speed only.  */
     ,FLUID_PARAM_TB_MIN_CELLS = 4  /* FLUID_JACOBI_TB fuses sweeps only on slabs of at least this many cells
                                       (default 0: always); smaller ones run one-thread-per-cell sweeps   */
 };
@@ -177,6 +180,9 @@ int fluid_set_jacobi_variant(fluid_ctx *ctx, int variant);
  * if this beta has not been seen): 0 true division, 2 double-precision reciprocal, 3 two-term float reciprocal
  * where the right-hand side allows it (else as 2), 4 exact float reciprocal (beta a power of two, alpha 1). */
 int fluid_division_mode(fluid_ctx *ctx, float alpha, float beta, int *mode);
+/* Launch shapes whose strip height is still being measured (FLUID_PARAM_TB_AUTOTUNE), process-wide: a benchmark runs
+ * untimed steps until this reaches 0. */
+int fluid_autotune_pending(fluid_ctx *ctx, int *shapes_open);
 int fluid_set_param(fluid_ctx *ctx, int key, int value);
 
 /* ---- timing: HIP events on the context's stream around every operator -------

@@ -43,6 +43,11 @@ with F.FluidSolver(n, rank=P // 2 - 1 if P > 1 else 0, nranks=P) as s:
     for rows in rows_list:
         s.set_param(capi.PARAM_TB_ROWS, rows)
         s.step(2)
+        for _ in range(6):                  # let the library's strip-height tuner finish (rows = 0)
+            if rows or s.autotune_pending() == 0:
+                break
+            s.step(5)
+            s.synchronize()
         s.synchronize()
         s.timing_enable(True)
         s.timing_read(reset=True)
