@@ -794,7 +794,7 @@ struct TbGrid {
 
 // waves per SIMD the register allocator must leave room for (second launch-bound argument): the
 // kernel hides its latencies (memory, dependent packed operations) only by running other waves
-constexpr int tb_waves_per_simd(int T, int NV) { return NV == 2 ? (T <= 8 ? 4 : 2) : (T <= 4 ? 3 : 2); }
+constexpr int tb_waves_per_simd(int T, int NV) { return NV == 2 ? (T <= 8 ? 4 : T <= 12 ? 3 : 2) : (T <= 4 ? 3 : 2); }
 
 // blockIdx.z picks one of up to three independent solves of the same shape (u, v and density
 // diffusion): more waves per launch, hence taller strips and less pipeline-fill redundancy.
@@ -1355,7 +1355,7 @@ void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const T
 {
     const int rows = row_hi - row_lo;
     if (rows <= 0 || batch.count <= 0) return;
-    if (T == 16) nv = 2;
+    if (T == 16 || T == 12) nv = 2;
     const int HL = (T + nv - 1) / nv, VS = 64 - 2 * HL;
     const unsigned nvec = (n + nv - 1) / nv;
     rb_edge = rb_edge < 1 ? rb : (rb_edge > rb ? rb : rb_edge);
@@ -1386,6 +1386,11 @@ void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const T
         else if (divmode == 3) { FLUID_TB2(16, 3, 2); }
         else if (divmode == 2) { FLUID_TB2(16, 2, 2); }
         else { FLUID_TB2(16, 0, 2); }
+    }
+    else if (T == 12) {                                  // 2-column lanes, three waves per SIMD
+        if (divmode == 4) { FLUID_TB2(12, 4, 2); }
+        else if (divmode == 2 || divmode == 3) { FLUID_TB2(12, 2, 2); }
+        else { FLUID_TB2(12, 0, 2); }
     }
     else if (T == 8) { FLUID_TB(8) }
     else if (T == 4) { FLUID_TB(4) }

@@ -482,29 +482,57 @@ int tune_end(fluid_ctx* c)
     return FLUID_OK;
 }
 
-// Sweeps fused into the next launch of a solve that has `room` sweeps it can still run (remaining sweeps,
-// and on slabs the valid reach).  Greedy: the deepest launch that fits.
-int pick_sweeps(const fluid_ctx* c, int room, bool canonical, bool small, long long slab_cells, bool all_mode4)
+// Sweeps fused into the next launch of a solve with `remaining` sweeps to go, of which `room` can run before rows must be
+// exchanged (slabs; = remaining on one GPU).  Depths 16 / 12 / 8 / 4 / 2 exist (2-column lanes, fp32 storage for 16 and
+// 12).  Per sweep the deep launches are the cheap ones where they pay at all, and a shallow remainder is dear (measured,
+// us per sweep of a pressure solve at 4096^2: 4.26 at 16, 4.05 at 12, 5.02 at 8; at 8192^2 13.6 / 16.3 / 23.5), so the
+// depths of a solve are PLANNED: the multiset of allowed depths that adds up to `remaining` at the least estimated cost,
+// deepest first -- 40 sweeps run as 16 + 12 + 12 rather than 16 + 16 + 8.
+//   - 16 and 12 pay on grids (or slabs) of 8 M cells and more; for the general form (a double-precision multiply per
+//     cell: bound by arithmetic, which deeper blocking only adds to) only once a field outgrows the Infinity Cache
+//     (96 MiB rule).  16 additionally wants rows: on a 1024-row slab 12 beats it (3.3 against 3.8 us per sweep).
+//   - FLUID_PARAM_TB_T16_MIN_CELLS replaces the size rules by one floor (0: always), so that tests can run the deep
+//     kernels of either form on grids the oracle finishes in milliseconds.
+//   - fp16 storage rounds once per launch, so its schedule is part of the result and stays the greedy 8 / 4 / 2 one.
+int pick_sweeps(const fluid_ctx* c, int remaining, int room, bool canonical, bool small, long long slab_cells, bool all_mode4)
 {
     // the fused kernel addresses a field through 32-bit buffer offsets: fields of 2 GiB and more
     // (beyond ~23000^2 in fp32) take single-sweep launches
     if (c->variant != fluid::JACOBI_TB || small || c->field_bytes >= 0x7F000000ull) return 1;
-    // 16 sweeps per launch exist for 2-column lanes and fp32 storage (fp16 results depend on the
-    // launch schedule, which stays the 8-sweep one)
-    // -- where they pay: the pressure form (a packed multiply per pair) is bound by memory at every
-    // size; the general form (a double-precision multiply per cell) is bound by arithmetic, which
-    // deeper blocking only adds to, until the fields outgrow the 256 MB Infinity Cache.  Grids (or slabs)
-    // under 8 M cells do not have the rows to fill the chip with 16-sweep strips (measured: 8 wins up to 3072^2).
-    // FLUID_PARAM_TB_T16_MIN_CELLS replaces both size rules by one floor (0: always), so that tests can
-    // run the 16-sweep kernels of either form on grids the oracle finishes in milliseconds.
-    if (room >= 16 && c->tb_max_t >= 16 && c->tb_nv == 2 && !canonical) {
-        const bool pays = c->tb_t16_min_cells >= 0
-                              ? slab_cells >= c->tb_t16_min_cells
-                              : slab_cells >= (8ll << 20) &&
-                                    (all_mode4 || (unsigned long long)slab_cells * c->esz > (96ull << 20));
-        if (pays) return 16;
+    room = std::min(room, remaining);
+    const int greedy = (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
+    if (canonical || c->tb_nv != 2 || c->tb_max_t < 12 || room < 12 || (remaining & 1)) return greedy;
+    const bool pays = c->tb_t16_min_cells >= 0 ? slab_cells >= c->tb_t16_min_cells
+                                               : slab_cells >= (8ll << 20) &&
+                                                     (all_mode4 || (unsigned long long)slab_cells * c->esz > (96ull << 20));
+    if (!pays) return greedy;
+    const long long slab_rows = slab_cells / std::max(c->n, 1);
+    static const int depth[5] = {16, 12, 8, 4, 2};
+    static const double per_sweep[5] = {1.00, 1.04, 1.30, 2.6, 5.0};      // relative cost of one sweep at that depth
+    const double per_launch = 0.5;
+    bool allowed[5] = {c->tb_max_t >= 16 && (c->tb_t16_min_cells >= 0 || slab_rows >= 3000), true, c->tb_max_t >= 8,
+                       c->tb_max_t >= 4, true};
+    // least cost to run exactly r sweeps (r even)
+    std::vector<double> cost(remaining + 1, 1e300);
+    cost[0] = 0.0;
+    for (int r = 2; r <= remaining; r += 2)
+        for (int k = 0; k < 5; ++k) {
+            if (!allowed[k] || depth[k] > r) continue;
+            const double v = cost[r - depth[k]] + depth[k] * per_sweep[k] + per_launch;
+            if (v < cost[r] - 1e-9) cost[r] = v;
+        }
+    // the plan's launches, deepest first; take the deepest one that fits the room
+    int best = 0;
+    for (int r = remaining; r > 0;) {
+        int pickd = 0;
+        for (int k = 0; k < 5 && !pickd; ++k)
+            if (allowed[k] && depth[k] <= r && std::fabs(cost[r - depth[k]] + depth[k] * per_sweep[k] + per_launch - cost[r]) < 1e-9)
+                pickd = depth[k];
+        if (!pickd) break;
+        if (pickd <= room) best = std::max(best, pickd);
+        r -= pickd;
     }
-    return (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
+    return best ? best : greedy;
 }
 
 // One Jacobi solve of the step: field x (first guess in, result out), right-hand
@@ -595,7 +623,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
     const bool small = (canonical ? (long long)c->n * c->n : slab_cells * count) < c->tb_min_cells;
     for (int k = 0; k < iters;) {
         const int remaining = iters - k;
-        auto pick = [&](int room) { return pick_sweeps(c, room, canonical, small, slab_cells, all_mode4); };
+        auto pick = [&](int room) { return pick_sweeps(c, remaining, room, canonical, small, slab_cells, all_mode4); };
         const int wantT = canonical ? pick(remaining) : 1;     // slabs with fp16 storage keep halo >= 8 (fluid_create_ex)
         if (r < wantT) {
             const int depth = std::max(wantT, std::min(c->halo, remaining + final_reach));
@@ -952,7 +980,7 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
         const bool small = (canonical ? (long long)c->n * c->n : slab_cells) < c->tb_min_cells;
         std::vector<int> launches;
         for (int left = iters; left > 0;) {
-            launches.push_back(pick_sweeps(c, left, canonical, small, slab_cells, /*all_mode4=*/false));
+            launches.push_back(pick_sweeps(c, left, left, canonical, small, slab_cells, /*all_mode4=*/false));
             left -= launches.back();
         }
         // about eight sweeps behind each reduction (whole launches; single-sweep kernels: eight launches)
@@ -1288,7 +1316,7 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
     TRY(check_ctx(c));
     switch (key) {
     case FLUID_PARAM_TB_MAX_SWEEPS:
-        if (value != 16 && value != 8 && value != 4 && value != 2) return fail(FLUID_E_INVALID, "TB_MAX_SWEEPS must be 16, 8, 4 or 2");
+        if (value != 16 && value != 12 && value != 8 && value != 4 && value != 2) return fail(FLUID_E_INVALID, "TB_MAX_SWEEPS must be 16, 12, 8, 4 or 2");
         c->tb_max_t = value;
         return FLUID_OK;
     case FLUID_PARAM_TB_ROWS:

@@ -56,3 +56,29 @@ def rnd(rng, n, lo=-1.0, hi=1.0):
 def oracle():
     from oracle.oracle import Oracle
     return Oracle()
+
+
+def tb_schedule(iters, max_t, deep=True):
+    """Launch depths of one fp32 solve through the fused Jacobi kernel, as fluid_solver.hip plans them
+    (pick_sweeps): where deep launches pay (`deep`: large grids, or PARAM_TB_T16_MIN_CELLS = 0 in tests) the
+    multiset of depths 16 / 12 / 8 / 4 / 2 (<= max_t) that adds up to the sweeps left at the least estimated
+    cost, deepest first; otherwise (and for remainders below 12) greedy 8 / 4 / 2."""
+    depth = (16, 12, 8, 4, 2)
+    w = (1.00, 1.04, 1.30, 2.6, 5.0)
+    out = []
+    left = iters
+    while left:
+        greedy = next(t for t in (8, 4, 2) if t <= min(max_t, left))
+        if not deep or max_t < 12 or left < 12:
+            t = greedy
+        else:
+            ok = [d <= max_t for d in depth]
+            cost = [0.0] + [1e300] * left
+            for r in range(2, left + 1, 2):
+                for k, d in enumerate(depth):
+                    if ok[k] and d <= r:
+                        cost[r] = min(cost[r], cost[r - d] + d * w[k] + 0.5)
+            t = next(d for k, d in enumerate(depth) if ok[k] and d <= left and abs(cost[left - d] + d * w[k] + 0.5 - cost[left]) < 1e-9)
+        out.append(t)
+        left -= t
+    return out

@@ -29,8 +29,8 @@ def crc(a):
 
 @pytest.mark.parametrize("form", ["pressure", "viscosity", "density"])
 def test_40_sweep_solve_at_8192_matches_oracle(F, oracle, form):
-    """FluidSequential.c:85-104 at N = 8190: the default schedule is 16 + 16 + 8 sweeps per launch for both
-    forms (k_jacobi_tb<16,4,2> / <16,2,2> and the <8,...> remainder)."""
+    """FluidSequential.c:85-104 at N = 8190: the default schedule is 16 + 12 + 12 sweeps per launch for both
+    forms (k_jacobi_tb<16,4,2> / <16,2,2> and <12,4,2> / <12,2,2>)."""
     n = 8190
     rng = np.random.default_rng({"pressure": 1, "viscosity": 2, "density": 3}[form])
     b, (alpha, beta) = {"pressure": (0, (1.0, 4.0)), "viscosity": (1, F.coefficients(n, DT, VISC)),
@@ -43,7 +43,7 @@ def test_40_sweep_solve_at_8192_matches_oracle(F, oracle, form):
         s.diffuse(b, "u", "v", alpha, beta, 40)
         t = s.timing_read(reset=True)
         got = s.download("u")
-    assert t["jacobi_launches"] == 3 and t["sweeps"] == 40, "expected 16 + 16 + 8 sweeps, got %r" % (t,)
+    assert t["jacobi_launches"] == 3 and t["sweeps"] == 40, "expected 16 + 12 + 12 sweeps, got %r" % (t,)
     oracle.diffuse(b, x, x0, alpha, beta, 40)
     assert_bit_equal(got, x, "40-sweep %s solve at 8192^2" % form)
 
@@ -87,7 +87,7 @@ def test_two_steps_at_8192_match_oracle_and_two_slabs(F, oracle):
         body(s)
         t = s.timing_read()
         one = {k: s.download(k) for k in ("u", "v", "dens", "u_prev", "v_prev", "dens_prev")}
-    # per step: the three diffusions share launches (16+16+8), each projection has its own 16+16+8
+    # per step: the three diffusions share launches (16+12+12), each projection has its own 16+12+12
     assert t["jacobi_launches"] == 2 * 9 and t["sweeps"] == 2 * 200, t
     got, fab = run_ranks(n, 2, 0, f, body, jacobi=3)
     for k in ("u", "v", "dens"):

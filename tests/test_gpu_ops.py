@@ -4,7 +4,7 @@ reference.  Bar: bit-exact (stricter than the 1e-5 relative of north_star)."""
 import numpy as np
 import pytest
 
-from conftest import assert_bit_equal, load_golden, rnd
+from conftest import assert_bit_equal, load_golden, rnd, tb_schedule
 
 pytestmark = pytest.mark.gpu
 
@@ -211,17 +211,7 @@ TB_SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 14, 61, 64, 95, 96, 97, 111, 112, 113, 119, 
             223, 224, 225, 239, 240, 241, 247, 248, 249, 255, 256, 257, 480, 481, 1022]
 
 
-def tb_schedule(iters, max_t):
-    """launch depths of one solve: greedy, deepest first (fluid_solver.hip: pick_sweeps)"""
-    out = []
-    while iters:
-        t = next(t for t in (16, 8, 4, 2) if t <= min(max_t, iters))
-        out.append(t)
-        iters -= t
-    return out
-
-
-@pytest.mark.parametrize("lane_cols,max_t,fast_div", [(2, 16, 1), (2, 16, 2), (2, 16, 0), (2, 8, 1), (2, 8, 2), (2, 4, 2), (2, 2, 1),
+@pytest.mark.parametrize("lane_cols,max_t,fast_div", [(2, 16, 1), (2, 16, 2), (2, 16, 0), (2, 12, 2), (2, 12, 0), (2, 8, 1), (2, 8, 2), (2, 4, 2), (2, 2, 1),
                                                       (4, 8, 1), (4, 8, 2), (4, 4, 2), (4, 2, 2)])
 @pytest.mark.parametrize("n", TB_SIZES)
 def test_temporal_blocking_matches_oracle(F, oracle, n, lane_cols, max_t, fast_div):
@@ -248,9 +238,9 @@ def test_temporal_blocking_matches_oracle(F, oracle, n, lane_cols, max_t, fast_d
                 s.timing_read(reset=True)
                 s.diffuse(b, "u", "v", alpha, beta, iters)
                 t = s.timing_read(reset=True)
-                assert t["jacobi_launches"] == len(tb_schedule(iters, max_t)) and t["sweeps"] == iters, \
-                    "schedule %r expected for %d sweeps at max_t=%d, got %d launches" % (
-                        tb_schedule(iters, max_t), iters, max_t, t["jacobi_launches"])
+                plan = tb_schedule(iters, max_t, deep=lane_cols == 2)
+                assert t["jacobi_launches"] == len(plan) and t["sweeps"] == iters, \
+                    "schedule %r expected for %d sweeps at max_t=%d, got %d launches" % (plan, iters, max_t, t["jacobi_launches"])
                 want = x.copy()
                 oracle.diffuse(b, want, x0, alpha, beta, iters)
                 assert_bit_equal(s.download("u"), want,
@@ -314,7 +304,7 @@ def test_temporal_blocking_reciprocal_division_is_exact(F, oracle, beta):
                                      "beta=%g fast=%d %s alpha=%g" % (beta, fast, kind, alpha))
 
 
-@pytest.mark.parametrize("max_t", [16, 8, 2])
+@pytest.mark.parametrize("max_t", [16, 12, 8, 2])
 @pytest.mark.parametrize("n", [97, 300, 1022])
 def test_two_term_division_only_where_the_right_hand_side_allows_it(F, oracle, n, max_t):
     """Division mode 3 (two packed float instructions) is exact for dividends that are zero or at least

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, assert_bit_equal, assert_close_fp32, load_golden, rnd
+from conftest import GOLDEN, assert_bit_equal, assert_close_fp32, load_golden, rnd, tb_schedule
 
 pytestmark = pytest.mark.gpu
 DT, VISC, DIFF = 0.016, 0.0025, 0.1
@@ -85,7 +85,7 @@ def test_step_vs_oracle(F, oracle, n):
 
 
 @pytest.mark.parametrize("fast_div", [2, 1])
-@pytest.mark.parametrize("lane_cols,max_t", [(2, 16), (2, 8), (4, 8), (4, 2)])
+@pytest.mark.parametrize("lane_cols,max_t", [(2, 16), (2, 12), (2, 8), (4, 8), (4, 2)])
 @pytest.mark.parametrize("n", [61, 126, 300])
 def test_steps_through_the_fused_kernel_on_signed_zero_fields(F, oracle, n, lane_cols, max_t, fast_div):
     """Whole steps with the fused Jacobi kernel forced on (it is the default only on large grids), on
@@ -99,7 +99,7 @@ def test_steps_through_the_fused_kernel_on_signed_zero_fields(F, oracle, n, lane
     u, v, dens, u0, v0, dens0 = (rng.choice(vals, size=(n + 2, n + 2)).astype(np.float32) for _ in range(6))
     params = {capi.PARAM_TB_MIN_CELLS: 0, capi.PARAM_TB_LANE_COLUMNS: lane_cols, capi.PARAM_TB_MAX_SWEEPS: max_t,
               capi.PARAM_TB_T16_MIN_CELLS: 0, capi.PARAM_TB_FAST_DIVISION: fast_div}
-    per_solve = len([t for t in (16, 16, 8) if t <= max_t]) if max_t == 16 else 40 // max_t
+    per_solve = len(tb_schedule(40, max_t, deep=lane_cols == 2))
     with F.FluidSolver(n, params=params) as s:
         s.upload(u=u, v=v, dens=dens, u_prev=u0, v_prev=v0, dens_prev=dens0)
         s.step(1, use_sources=True)

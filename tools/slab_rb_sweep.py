@@ -22,16 +22,20 @@ for P in [int(x) for x in sys.argv[2:]] or [8, 4]:
         x = np.random.default_rng(0).random((n + 2, n + 2), dtype=np.float32)
         s.upload_rows("u", x, max(lo - 64, 0), min(hi + 64, n + 2))
         s.upload_rows("v", x, max(lo - 64, 0), min(hi + 64, n + 2))
+        if os.environ.get("TB_T"):
+            s.set_param(capi.PARAM_TB_MAX_SWEEPS, int(os.environ["TB_T"]))
+            s.set_param(capi.PARAM_TB_T16_MIN_CELLS, 0)
         av, bv = F.coefficients(n, 0.016, 0.0025)
+        sweeps = int(os.environ.get("SWEEPS", "40"))
         for form, b, alpha, beta in (("pressure", 0, 1.0, 4.0), ("general", 1, av, bv)):
             out = []
-            for rb in (0, 16, 24, 32, 40, 48, 56, 64, 72, 80, 96, 112, 128, 160, 192, 256):
+            for rb in (0, 32, 48, 56, 64, 72, 80, 88, 96, 104, 112, 128, 144, 160, 192, 256):
                 s.set_param(capi.PARAM_TB_ROWS, rb)
-                s.diffuse(b, "u", "v", alpha, beta, 40)
+                s.diffuse(b, "u", "v", alpha, beta, sweeps)
                 s.timing_enable(True)
                 s.timing_read(reset=True)
                 for _ in range(4):
-                    s.diffuse(b, "u", "v", alpha, beta, 40)
+                    s.diffuse(b, "u", "v", alpha, beta, sweeps)
                 t = s.timing_read(reset=True)
                 s.timing_enable(False)
                 out.append("%d:%.2f" % (rb, t["jacobi_ms"] * 1e3 / t["sweeps"]))
