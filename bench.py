@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--tb-sweeps", type=int, default=0, help="temporal blocking: most sweeps per launch (16, 8, 4, 2; 0 = default)")
     ap.add_argument("--tb-rows", type=int, default=0, help="temporal blocking: rows per wave strip (0 = auto)")
     ap.add_argument("--fast-division", type=int, default=-1, help="FLUID_PARAM_TB_FAST_DIVISION (default: library's)")
+    ap.add_argument("--t16-min-cells", type=int, default=-1, help="FLUID_PARAM_TB_T16_MIN_CELLS (default: library's rule)")
     ap.add_argument("--halo", type=int, default=0, help="multi-GPU ghost-zone depth (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scaling-base", action="store_true")
@@ -251,6 +252,8 @@ def main():
             s.set_param(1, a.tb_rows)
         if a.fast_division >= 0:
             s.set_param(3, a.fast_division)
+        if a.t16_min_cells >= 0:
+            s.set_param(7, a.t16_min_cells)
         return s
 
     tuning = {}

@@ -488,9 +488,9 @@ int tune_end(fluid_ctx* c)
 // us per sweep of a pressure solve at 4096^2: 4.26 at 16, 4.05 at 12, 5.02 at 8; at 8192^2 13.6 / 16.3 / 23.5), so the
 // depths of a solve are PLANNED: the multiset of allowed depths that adds up to `remaining` at the least estimated cost,
 // deepest first -- 40 sweeps run as 16 + 12 + 12 rather than 16 + 16 + 8.
-//   - 16 and 12 pay on grids (or slabs) of 8 M cells and more; for the general form (a double-precision multiply per
-//     cell: bound by arithmetic, which deeper blocking only adds to) only once a field outgrows the Infinity Cache
-//     (96 MiB rule).  16 additionally wants rows: on a 1024-row slab 12 beats it (3.3 against 3.8 us per sweep).
+//   - 12 pays on grids (or slabs) of 8 M cells and more.  16 too, but for the general form (a double-precision multiply
+//     per cell: bound by arithmetic, which deeper blocking only adds to) only once a field outgrows the Infinity Cache
+//     (96 MiB rule), and it wants rows: on a 1024-row slab 12 beats it (3.3 against 3.8 us per sweep).
 //   - FLUID_PARAM_TB_T16_MIN_CELLS replaces the size rules by one floor (0: always), so that tests can run the deep
 //     kernels of either form on grids the oracle finishes in milliseconds.
 //   - fp16 storage rounds once per launch, so its schedule is part of the result and stays the greedy 8 / 4 / 2 one.
@@ -502,16 +502,16 @@ int pick_sweeps(const fluid_ctx* c, int remaining, int room, bool canonical, boo
     room = std::min(room, remaining);
     const int greedy = (room >= 8 && c->tb_max_t >= 8) ? 8 : (room >= 4 && c->tb_max_t >= 4) ? 4 : room >= 2 ? 2 : 1;
     if (canonical || c->tb_nv != 2 || c->tb_max_t < 12 || room < 12 || (remaining & 1)) return greedy;
-    const bool pays = c->tb_t16_min_cells >= 0 ? slab_cells >= c->tb_t16_min_cells
-                                               : slab_cells >= (8ll << 20) &&
-                                                     (all_mode4 || (unsigned long long)slab_cells * c->esz > (96ull << 20));
-    if (!pays) return greedy;
+    const bool forced = c->tb_t16_min_cells >= 0;
+    const bool big = forced ? slab_cells >= c->tb_t16_min_cells : slab_cells >= (8ll << 20);
+    if (!big) return greedy;
     const long long slab_rows = slab_cells / std::max(c->n, 1);
+    // 16: the pressure form always; the general form once a field outgrows the Infinity Cache; never on short slabs
+    const bool pays16 = forced || ((all_mode4 || (unsigned long long)slab_cells * c->esz > (96ull << 20)) && slab_rows >= 3000);
     static const int depth[5] = {16, 12, 8, 4, 2};
     static const double per_sweep[5] = {1.00, 1.04, 1.30, 2.6, 5.0};      // relative cost of one sweep at that depth
     const double per_launch = 0.5;
-    bool allowed[5] = {c->tb_max_t >= 16 && (c->tb_t16_min_cells >= 0 || slab_rows >= 3000), true, c->tb_max_t >= 8,
-                       c->tb_max_t >= 4, true};
+    bool allowed[5] = {c->tb_max_t >= 16 && pays16, true, c->tb_max_t >= 8, c->tb_max_t >= 4, true};
     // least cost to run exactly r sweeps (r even)
     std::vector<double> cost(remaining + 1, 1e300);
     cost[0] = 0.0;

@@ -35,11 +35,21 @@ def main():
         print("kernel stats ->", dst)
     if os.path.exists(os.path.join(root, "bench_line.json")):
         shutil.copy(os.path.join(root, "bench_line.json"), "profiles/%s_%s%s_bench.json" % (tag, grid, suffix))
+    # bench.py first lets the library's strip-height tuner finish in a throw-away context (trial launches with
+    # deliberately varied strip heights): only the later half of each kernel's dispatches in a pass -- the warm-up and
+    # the timed steps -- goes into the means
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(dict)
     for f in glob.glob(os.path.join(root, "*", "*_counter_collection.csv")):
-        for r in csv.DictReader(open(f)):
+        rows = list(csv.DictReader(open(f)))
+        ids = collections.defaultdict(set)
+        for r in rows:
+            ids[short(r["Kernel_Name"])].add(int(r["Dispatch_Id"]))
+        late = {k: set(sorted(v)[len(v) // 2:]) for k, v in ids.items()}
+        for r in rows:
             k = short(r["Kernel_Name"])
+            if int(r["Dispatch_Id"]) not in late[k]:
+                continue
             pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
                 dur[k][r["Dispatch_Id"]] = (float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
