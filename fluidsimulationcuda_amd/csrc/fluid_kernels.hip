@@ -1389,7 +1389,8 @@ void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const T
     }
     else if (T == 12) {                                  // 2-column lanes, three waves per SIMD
         if (divmode == 4) { FLUID_TB2(12, 4, 2); }
-        else if (divmode == 2 || divmode == 3) { FLUID_TB2(12, 2, 2); }
+        else if (divmode == 3) { FLUID_TB2(12, 3, 2); }
+        else if (divmode == 2) { FLUID_TB2(12, 2, 2); }
         else { FLUID_TB2(12, 0, 2); }
     }
     else if (T == 8) { FLUID_TB(8) }
