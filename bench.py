@@ -115,6 +115,23 @@ def measure(solver, dist, world, steps, warmup, iters):
     return timed_steps(solver, dist, world, steps, iters)
 
 
+def pressure_solve_rate(solver, iters, reps):
+    """SURVEY.md 8(d)(i) on its own: the mean time of one sweep (set_bnd included) of the pressure solve -- alpha 1,
+    beta 4, b 0, first guess p = 0 -- measured over `reps` solves of `iters` sweeps on the fields the timed steps left
+    behind: computeDivergenceAndPressure(u, v, p, div) as its own kernel (which also marks p zero), then the solve, HIP
+    events around the solve only.  (Inside a step the divergence rides in the solve's first launch since round 2, so the
+    in-step solve time is no longer sweeps alone; it is reported beside this as in_step_pressure_solve.)
+    Returns (ms in solves, sweeps)."""
+    solver.timing_enable(True)
+    solver.timing_read(reset=True)
+    for _ in range(reps):
+        solver.computeDivergenceAndPressure("u", "v", "u_prev", "v_prev")
+        solver.diffuse(0, "u_prev", "v_prev", 1.0, 4.0, iters)
+    t = solver.timing_read(reset=True)
+    solver.timing_enable(False)
+    return t["jacobi_ms"], t["sweeps"]
+
+
 def measure_ordinary(solver, fields, steps, warmup, iters):
     """Sources re-injected before every step (one GPU): device copies of the three source fields are written into
     u_prev / v_prev / dens_prev, then one step consumes them.  Returns timed_steps()'s tuple plus the time the
@@ -243,9 +260,11 @@ def main():
     cells = grid * grid
     exchange = a.exchange if a.exchange != "auto" else ("rccl" if a.backend == "nccl" else "torch")
 
-    def make(n_):
+    def make(n_, fuse_divergence=True):
         s = SlabSolver(n_, rank=rank, nranks=world, halo=a.halo, jacobi=a.variant,
                        storage=1 if a.dtype == "f16" else 0, exchange=exchange)
+        if not fuse_divergence:
+            s.set_param(9, 0)
         if a.tb_sweeps:
             s.set_param(0, a.tb_sweeps)
         if a.tb_rows:
@@ -272,21 +291,24 @@ def main():
         for _ in range(4):
             s.step(6, iters=a.iters)
             steps += 6
+            if world == 1:
+                pressure_solve_rate(s, a.iters, 8)          # the stand-alone solve's launch shapes too
             s.synchronize()
             if world == 1 and s.autotune_pending() == 0:
                 break
         tuning[n_] = {"untimed_steps": steps, "shapes_still_open": s.autotune_pending()}
         s.close()
 
-    def run(n_, steps, warmup):
+    def run(n_, steps, warmup, fuse_divergence=True):
         tune(n_)
         fields = initialize_parameters(n_, seed=a.seed)     # same seed on every rank
-        s = make(n_)
+        s = make(n_, fuse_divergence)
         s.load_global(**fields)
         out = measure(s, dist, world, steps, warmup, a.iters)
+        solve = pressure_solve_rate(s, a.iters, max(steps // 2, 4)) if world == 1 else None
         calls = s.exchange_calls()
         s.close()
-        return out, fields, calls
+        return out + (solve,), fields, calls
 
     def run_ordinary(n_, steps, warmup):
         tune(n_)
@@ -294,20 +316,23 @@ def main():
         s = make(n_)
         s.load_global(**fields)
         out = measure_ordinary(s, fields, steps, warmup, a.iters)
+        solve = pressure_solve_rate(s, a.iters, max(steps // 2, 4))
         s.close()
-        return out
+        return out + (solve,)
 
-    def rates(elapsed, jac_ms, prs_ms, t, steps, cells_):
+    def rates(elapsed, jac_ms, prs_ms, t, steps, cells_, solve=None):
         t_sweep = jac_ms * 1e-3 / max(t["sweeps"], 1)
-        t_psweep = prs_ms * 1e-3 / max(t["pressure_sweeps"], 1)
+        t_instep = prs_ms * 1e-3 / max(t["pressure_sweeps"], 1)      # in-step pressure solves (with the fused divergence)
+        t_psweep = solve[0] * 1e-3 / max(solve[1], 1) if solve else t_instep
         cats = {k: t[k + "_ms"] / steps for k in ("source", "diffusion", "divergence", "projection", "advection")}
         return {"value": cells_ / t_psweep / 1e6, "ms_per_step": elapsed * 1e3 / steps, "kernel_ms_per_step": cats,
                 "us_per_jacobi_sweep": t_psweep * 1e6, "all_solves_value": cells_ / t_sweep / 1e6,
-                "all_solves_us_per_jacobi_sweep": t_sweep * 1e6, "t_sweep": t_sweep}
+                "all_solves_us_per_jacobi_sweep": t_sweep * 1e6, "t_sweep": t_sweep,
+                "in_step_pressure_us_per_sweep": t_instep * 1e6}
 
     if a.only_ordinary:
-        e, j, p, t, copy_ms = run_ordinary(n, a.steps, a.warmup)
-        r = rates(e, j, p, t, a.steps, cells)
+        e, j, p, t, copy_ms, solve = run_ordinary(n, a.steps, a.warmup)
+        r = rates(e, j, p, t, a.steps, cells, solve)
         print(json.dumps({"value_ordinary_data": r, "copy_ms_per_step": copy_ms}), flush=True)
         return
 
@@ -331,8 +356,8 @@ def main():
                     sys.exit("rank %d: %s differs between %d slabs and one context" % (rank, k, world))
         if rank == 0:
             print("check ok: %d slabs bit-identical to one context at %dx%d" % (world, grid, grid), file=sys.stderr)
-    (elapsed, jac_ms, prs_ms, t), fields, calls = run(n, a.steps, a.warmup)
-    r = rates(elapsed, jac_ms, prs_ms, t, a.steps, cells)
+    (elapsed, jac_ms, prs_ms, t, solve), fields, calls = run(n, a.steps, a.warmup)
+    r = rates(elapsed, jac_ms, prs_ms, t, a.steps, cells, solve)
     ms_step, t_sweep = r["ms_per_step"], r["t_sweep"]
     sweeps, field_launches = t["sweeps"], t["jacobi_field_launches"]
     bpc = BYTES_PER_CELL_SWEEP // (2 if a.dtype == "f16" else 1)
@@ -360,6 +385,15 @@ def main():
                                    "FluidSequential.c:192-234); 'projection' holds the gradient subtractions, the second "
                                    "one fused with the density advection"),
         "us_per_jacobi_sweep": r["us_per_jacobi_sweep"],
+        "value_definition": ("SURVEY.md 8(d)(i): W^2 / t_sweep over the 40-sweep pressure solve (alpha 1, beta 4, b 0, first guess 0), "
+                             "%d solves on the fields the timed steps left behind, HIP events around each solve; the divergence "
+                             "before it is a kernel of its own there" % (solve[1] // a.iters)) if solve else
+                            "W^2 / t_sweep over the pressure solves inside the timed steps (HIP events)",
+        "in_step_pressure_solve": {"us_per_jacobi_sweep": r["in_step_pressure_us_per_sweep"],
+                                   "value": cells / (r["in_step_pressure_us_per_sweep"] * 1e-6) / 1e6,
+                                   "note": "the 80 pressure sweeps of each timed step; on one GPU their first launch also computes "
+                                           "and stores the projection's divergence (no separate k_divergence pass), so this is "
+                                           "sweeps + divergence"},
         "all_solves": {"value": r["all_solves_value"], "unit": "Mcells/s", "us_per_jacobi_sweep": t_sweep * 1e6,
                        "note": "the same rate over all 200 sweeps of the step (3 diffusions, whose exact division "
                                "by 1+4a costs more than the pressure solve's multiply by 1/4, + 2 pressure solves)"},
@@ -411,11 +445,21 @@ def main():
     if tuning:
         line["autotune"] = dict(tuning[n], note="strip heights of the fused Jacobi kernel measured by the library in a throw-away "
                                 "context before the warm-up (FLUID_PARAM_TB_AUTOTUNE); results do not depend on them")
+    if world == 1 and a.variant == 3:
+        # the round-1 form of the step, for comparison across rounds: every operator a launch of its own
+        (e3, j3, p3, t3, _s3), _, _ = run(n, a.steps, a.warmup, fuse_divergence=False)
+        r3 = rates(e3, j3, p3, t3, a.steps, cells)
+        line["divergence_as_its_own_kernel"] = {
+            "ms_per_step": r3["ms_per_step"], "in_step_pressure_us_per_sweep": r3["in_step_pressure_us_per_sweep"],
+            "in_step_pressure_value": cells / (r3["in_step_pressure_us_per_sweep"] * 1e-6) / 1e6,
+            "all_solves_value": r3["all_solves_value"], "kernel_ms_per_step": r3["kernel_ms_per_step"],
+            "note": "FLUID_PARAM_FUSE_DIVERGENCE = 0: the same K steps with k_divergence as a separate pass, so that the "
+                    "pressure solves inside the steps are sweeps alone (how round 1 measured `value`)"}
     if calls:
         line["exchanges_per_rank"] = {"halo": calls[0], "gather": calls[1], "max": calls[2]}
     if world == 1 and not a.no_ordinary:
-        e2, j2, p2, t2, copy_ms = run_ordinary(n, a.steps, a.warmup)
-        r2 = rates(e2, j2, p2, t2, a.steps, cells)
+        e2, j2, p2, t2, copy_ms, solve2 = run_ordinary(n, a.steps, a.warmup)
+        r2 = rates(e2, j2, p2, t2, a.steps, cells, solve2)
         line["value_ordinary_data"] = {
             "value": r2["value"], "unit": "Mcells/s", "us_per_jacobi_sweep": r2["us_per_jacobi_sweep"],
             "all_solves_value": r2["all_solves_value"], "all_solves_us_per_jacobi_sweep": r2["all_solves_us_per_jacobi_sweep"],
@@ -426,8 +470,8 @@ def main():
                     "ordinary magnitudes instead of decaying towards zero" % copy_ms}
     if world == 1 and not a.no_scaling_base and grid != 8192:
         steps2 = max(a.steps // 4, 3)
-        (e2, j2, p2, t2), _, _ = run(8190, steps2, 2)
-        r2 = rates(e2, j2, p2, t2, steps2, 8192 * 8192)
+        (e2, j2, p2, t2, solve2), _, _ = run(8190, steps2, 2)
+        r2 = rates(e2, j2, p2, t2, steps2, 8192 * 8192, solve2)
         line["scaling_base"] = {"workload": "8192x8192 on 1 GPU", "value": r2["value"], "unit": "Mcells/s",
                                 "ms_per_step": r2["ms_per_step"], "all_solves_value": r2["all_solves_value"],
                                 "roofline_frac": BYTES_PER_CELL_SWEEP * 8192 * 8192 / r2["t_sweep"] / 1e9 / HBM_PEAK_GBS,

@@ -49,6 +49,7 @@ struct fluid_ctx {
     long long tb_min_cells = 0;                    // smaller slabs use single-sweep launches (never faster since the 2-column lanes)
     long long tb_t16_min_cells = -1;               // >= 0: 16-sweep launches on every slab of at least this many cells (tests, tuning);
                                                    // -1: the measured rule of pick_sweeps()
+    bool fuse_divergence = true;                   // a projection's divergence is computed inside its solve's first launch
     bool autotune = true;                          // strip heights of the fused kernel measured at run time (fluid_solver.hip: RbTuner)
     struct Trial { unsigned long long key; int cand; hipEvent_t a, b; };
     std::vector<Trial> trials;                     // launches being timed for the tuner

@@ -43,6 +43,13 @@ __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const half_t* p) { return keep_f32((float)*p); }
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(half_t* p, float v) { *p = (half_t)keep_f32(v); }
+// a value as it reads back after a store in the storage type (fp16 storage: rounded once; fp32: itself)
+template <typename S>
+__device__ __forceinline__ float as_stored(float v)
+{
+    if constexpr (sizeof(S) == 2) return keep_f32((float)(S)keep_f32(v));
+    else return v;
+}
 typedef half_t half4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 ld4(const half_t* p)
@@ -490,6 +497,9 @@ struct TbArgs {
     double yd;            // DIVMODE 2 (and 3's fallback): 1/beta rounded to double
     float lo;             // DIVMODE 3: lo = RN32(1/beta - hi); hi travels in `hi`
     float hi;
+    S* dc;                // DIVSRC: the divergence field + column offset, its buffer, and -0.5f * h
+    __amdgpu_buffer_rsrc_t bd;
+    float div_scale;
     unsigned sx, sy;      // sign masks: flip across vertical / horizontal walls
     float x0_inc;         // pending add_source increment of the right-hand side (-0.0f: none)
     bool st_rg_lane, is_lg;
@@ -620,10 +630,11 @@ __device__ __forceinline__ void tb_fix_columns(Vec<NV>& G, const TbArgs<S, NV>& 
 // interior ones; wall strips add the two ghost rows, enabled by a select on the offset.  A fixed
 // number of memory operations per step is what lets hipcc count them (see kBufOff).
 template <bool EDGE, bool WALL, typename S, int NV>
-__device__ __forceinline__ void tb_store(const Vec<NV>& G, int q, bool mine, const TbArgs<S, NV>& a, float v1, float vn)
+__device__ __forceinline__ void tb_store_to(S* oc, __amdgpu_buffer_rsrc_t bo, const Vec<NV>& G, int q, bool mine, const TbArgs<S, NV>& a,
+                                            float v1, float vn)
 {
     auto on = [](bool c, unsigned off) { return c ? off : kBufOff; };
-    buf_stv<NV>(a.oc, a.bo, on(mine, a.st_off) + (unsigned)q * a.row_bytes, G);
+    buf_stv<NV>(oc, bo, on(mine, a.st_off) + (unsigned)q * a.row_bytes, G);
     if (WALL) {
         Vec<NV> g = fxorv<NV>(G, a.sy);                  // ghost row = flipped wall row ...
         if (EDGE) {                                      // ... except its two corner cells
@@ -634,9 +645,40 @@ __device__ __forceinline__ void tb_store(const Vec<NV>& G, int q, bool mine, con
             for (int c = 0; c < NV; ++c)
                 if (a.st_rg_lane && a.cg == c) g.c[c] = cr;
         }
-        buf_stv<NV>(a.oc, a.bo, on(mine & (q == 1), a.st_off), g);                                        // row 0
-        buf_stv<NV>(a.oc, a.bo, on(mine & (q == a.n), a.st_off) + (unsigned)(a.n + 1) * a.row_bytes, g);  // row n+1
+        buf_stv<NV>(oc, bo, on(mine & (q == 1), a.st_off), g);                                        // row 0
+        buf_stv<NV>(oc, bo, on(mine & (q == a.n), a.st_off) + (unsigned)(a.n + 1) * a.row_bytes, g);  // row n+1
     }
+}
+template <bool EDGE, bool WALL, typename S, int NV>
+__device__ __forceinline__ void tb_store(const Vec<NV>& G, int q, bool mine, const TbArgs<S, NV>& a, float v1, float vn)
+{
+    tb_store_to<EDGE, WALL, S, NV>(a.oc, a.bo, G, q, mine, a, v1, vn);
+}
+
+// DIVSRC: the divergence of (u, v) on row t-1 (FluidSequential.c:151-152: (-0.5f*h) * (((uR - uL) + vD) - vU)) from the
+// rows the wave holds -- u row t-1, v rows t-2 and t -- for the first launch of a pressure solve, which then needs
+// no divergence kernel before it: the row becomes the launch's right-hand side and is stored for the later launches.
+template <int NV>
+__device__ __forceinline__ Vec<NV> tb_divergence(const Vec<NV>& u, const Vec<NV>& v_up, const Vec<NV>& v_dn, float scale)
+{
+    float g[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const float ur = c < NV - 1 ? u.c[c + 1] : lane_above0(u.c[0]);
+        const float ul = c > 0 ? u.c[c - 1] : lane_below0(u.c[NV - 1]);
+        g[c] = ur - ul;
+    }
+    Vec<NV> d;
+#pragma unroll
+    for (int p = 0; p < NV; p += 2) {
+        v2f s = {g[p], g[p + 1]};
+        s = s + (v2f){v_dn.c[p], v_dn.c[p + 1]};
+        s = s - (v2f){v_up.c[p], v_up.c[p + 1]};
+        s = s * scale;
+        d.c[p] = s.x;
+        d.c[p + 1] = s.y;
+    }
+    return d;
 }
 
 // the hand-over of a prefetched row into the pipeline, as register moves the compiler cannot see
@@ -671,9 +713,9 @@ __device__ __forceinline__ void tb_qshift(Vec<NV> (&Q)[N])
 // GEN = false: every row any stage touches at this step is interior -- a
 // branch-free body.  GEN = true (the few steps of a wall strip that sit on rows
 // 0 / n+1): per-stage checks, ghost rows of each stage regenerated from its rows 1 / n.
-template <int T, int DIVMODE, bool EDGE, bool WALL, bool GEN, int PH, typename S, int NV>
+template <int T, int DIVMODE, bool EDGE, bool WALL, bool GEN, int PH, typename S, int NV, bool DIVSRC = false>
 __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[T + 1], Vec<NV> (&PX)[3], Vec<NV> (&PQ)[3],
-                                        const TbArgs<S, NV>& a)
+                                        const TbArgs<S, NV>& a, Vec<NV> (&UR)[3], Vec<NV> (&VR)[3])
 {
     constexpr int UP = PH % 3, ME = (PH + 1) % 3, FR = (PH + 2) % 3;
     // stage 0: row t of x and x0, loaded three steps ago.  The hand-over is an opaque register move on
@@ -681,13 +723,19 @@ __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[
     // for it with copies at the loop's back edge -- copies of rows still in flight, i.e. a wait for
     // every outstanding load once per iteration.
     __builtin_amdgcn_sched_barrier(0);                   // (and not hoisted into the previous step either)
-    W[0][FR] = take<NV>(PX[PH]);
-    Q[0] = take<NV>(PQ[PH]);
+    if constexpr (DIVSRC) {
+        // the two prefetch slots carry u and v (the first guess is all +0 and is not read): rings of their last three rows
+        UR[FR] = take<NV>(PX[PH]);
+        VR[FR] = take<NV>(PQ[PH]);
+    } else {
+        W[0][FR] = take<NV>(PX[PH]);
+        Q[0] = take<NV>(PQ[PH]);
 #pragma unroll
-    for (int p = 0; p < NV; p += 2) {                    // x0 + dt*0 where an add_source was deferred, else x0 + (-0) = x0
-        const v2f q = (v2f){Q[0].c[p], Q[0].c[p + 1]} + a.x0_inc;
-        Q[0].c[p] = q.x;
-        Q[0].c[p + 1] = q.y;
+        for (int p = 0; p < NV; p += 2) {                // x0 + dt*0 where an add_source was deferred, else x0 + (-0) = x0
+            const v2f q = (v2f){Q[0].c[p], Q[0].c[p + 1]} + a.x0_inc;
+            Q[0].c[p] = q.x;
+            Q[0].c[p + 1] = q.y;
+        }
     }
     {   // refill the slot with row t+3: three steps of arithmetic cover the memory latency.  Rows past
         // the field's end and lanes past its width fall outside the buffer and read as 0.
@@ -699,6 +747,18 @@ __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[
     // them to the end of the unrolled iteration (shorter live ranges) and the wave then waits out a
     // full memory latency per iteration
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DIVSRC) {
+        // right-hand side row t-1 = divergence there; it is what stage 1 consumes at this step (Q[1]), and it is stored
+        // (with the ghost cells set_bnd(0, div) would give it) for the solve's later launches and as the step's v_prev
+        const int q = t - 1;
+        Vec<NV> D = tb_divergence<NV>(UR[ME], VR[UP], VR[FR], a.div_scale);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) D.c[c] = as_stored<S>(D.c[c]);     // fp16 storage: what a separate divergence pass would hand on
+        Q[1] = D;
+        float v1 = 0.f, vn = 0.f;
+        if (EDGE) tb_fix_columns<S, NV>(D, a, v1, vn, WALL);
+        tb_store_to<EDGE, (WALL || GEN), S, NV>(a.dc, a.bd, D, q, (q >= 1) & (q <= a.n) & (q >= a.q_lo) & (q < a.q_hi), a, v1, vn);
+    }
     if constexpr (!GEN) {
 #pragma unroll
         for (int s = 1; s <= T; ++s) {
@@ -736,10 +796,10 @@ __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[
     tb_qshift<T, T + 1, NV>(Q);
 }
 
-template <int T, int DIVMODE, bool EDGE, bool WALL, typename S, int NV>
+template <int T, int DIVMODE, bool EDGE, bool WALL, typename S, int NV, bool DIVSRC = false>
 __device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs<S, NV>& a)
 {
-    Vec<NV> W[T][3], Q[T + 1], PX[3], PQ[3];
+    Vec<NV> W[T][3], Q[T + 1], PX[3], PQ[3], UR[3], VR[3];
     Vec<NV> zero;
 #pragma unroll
     for (int c = 0; c < NV; ++c) zero.c[c] = 0.f;
@@ -747,6 +807,8 @@ __device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs<S, NV>& a)
     for (int s = 0; s < T; ++s) { W[s][0] = zero; W[s][1] = zero; W[s][2] = zero; }
 #pragma unroll
     for (int s = 0; s <= T; ++s) Q[s] = zero;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { UR[d] = zero; VR[d] = zero; }
 #pragma unroll
     for (int d = 0; d < 3; ++d) {                        // rows t0, t0+1, t0+2 in flight before the first step
         const unsigned off = a.ld_off + (unsigned)(t0 + d) * a.row_bytes;
@@ -757,6 +819,7 @@ __device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs<S, NV>& a)
         // for a row at the top of the loop counts 7 younger operations on both paths into it instead
         // of draining the queue
         buf_stv<NV>(a.oc, a.bo, kBufOff, zero);
+        if constexpr (DIVSRC) buf_stv<NV>(a.dc, a.bd, kBufOff, zero);      // (a step of this variant stores a second row)
         __builtin_amdgcn_sched_barrier(0);               // in this order
     }
     // whole triples only: up to two surplus steps load nothing (rows past the field) and store nothing
@@ -768,21 +831,21 @@ __device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs<S, NV>& a)
     int t = t0;
     if constexpr (WALL) {
         for (; t <= t1 && t < T + 1; t += 3) {
-            tb_step<T, DIVMODE, EDGE, WALL, true, 0>(t, W, Q, PX, PQ, a);
-            tb_step<T, DIVMODE, EDGE, WALL, true, 1>(t + 1, W, Q, PX, PQ, a);
-            tb_step<T, DIVMODE, EDGE, WALL, true, 2>(t + 2, W, Q, PX, PQ, a);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 0, S, NV, DIVSRC>(t, W, Q, PX, PQ, a, UR, VR);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 1, S, NV, DIVSRC>(t + 1, W, Q, PX, PQ, a, UR, VR);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 2, S, NV, DIVSRC>(t + 2, W, Q, PX, PQ, a, UR, VR);
         }
     }
     for (; t <= t1 && (!WALL || t + 1 <= a.n); t += 3) {
-        tb_step<T, DIVMODE, EDGE, WALL, false, 0>(t, W, Q, PX, PQ, a);
-        tb_step<T, DIVMODE, EDGE, WALL, false, 1>(t + 1, W, Q, PX, PQ, a);
-        tb_step<T, DIVMODE, EDGE, WALL, false, 2>(t + 2, W, Q, PX, PQ, a);
+        tb_step<T, DIVMODE, EDGE, WALL, false, 0, S, NV, DIVSRC>(t, W, Q, PX, PQ, a, UR, VR);
+        tb_step<T, DIVMODE, EDGE, WALL, false, 1, S, NV, DIVSRC>(t + 1, W, Q, PX, PQ, a, UR, VR);
+        tb_step<T, DIVMODE, EDGE, WALL, false, 2, S, NV, DIVSRC>(t + 2, W, Q, PX, PQ, a, UR, VR);
     }
     if constexpr (WALL) {
         for (; t <= t1; t += 3) {
-            tb_step<T, DIVMODE, EDGE, WALL, true, 0>(t, W, Q, PX, PQ, a);
-            tb_step<T, DIVMODE, EDGE, WALL, true, 1>(t + 1, W, Q, PX, PQ, a);
-            tb_step<T, DIVMODE, EDGE, WALL, true, 2>(t + 2, W, Q, PX, PQ, a);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 0, S, NV, DIVSRC>(t, W, Q, PX, PQ, a, UR, VR);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 1, S, NV, DIVSRC>(t + 1, W, Q, PX, PQ, a, UR, VR);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 2, S, NV, DIVSRC>(t + 2, W, Q, PX, PQ, a, UR, VR);
         }
     }
 }
@@ -798,10 +861,11 @@ constexpr int tb_waves_per_simd(int T, int NV) { return NV == 2 ? (T <= 8 ? 4 : 
 
 // blockIdx.z picks one of up to three independent solves of the same shape (u, v and density
 // diffusion): more waves per launch, hence taller strips and less pipeline-fill redundancy.
-template <int T, int DIVMODE, int NV, typename S>
+template <int T, int DIVMODE, int NV, typename S, bool DIVSRC = false>
 __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbBatch batch, int pitch, int n, int row_lo,
                                                                              int row_hi, int rb, int rb_edge, TbGrid g)
 {
+    static_assert(!DIVSRC || DIVMODE == 4, "the divergence-sourced launch is the first launch of a pressure solve");
     // Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  The
     // grid is one-dimensional, a multiple of 8 long, and renumbered so that XCD k works through the
     // k-th contiguous eighth of the (window, strip group) list, windows fastest: the blocks an XCD
@@ -863,9 +927,14 @@ __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbB
         const unsigned field_bytes = (unsigned)((size_t)(n + 2) * (size_t)pitch * sizeof(S));    // < 2 GiB (launch_jacobi_tb)
         // a first guess known to be all +0 (sources after step 0, the pressure) is never read: an
         // empty descriptor makes every load of it return 0
-        a.bx = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(x), 0, batch.x_zero[blockIdx.z] ? 0u : field_bytes, 0x00020000);
+        // (DIVSRC: x and x0 are u and v, both read; the first guess is +0 by definition and lives nowhere)
+        a.bx = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(x), 0, (batch.x_zero[blockIdx.z] && !DIVSRC) ? 0u : field_bytes, 0x00020000);
         a.br = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(x0), 0, field_bytes, 0x00020000);
         a.bo = __builtin_amdgcn_make_buffer_rsrc(out, 0, field_bytes, 0x00020000);
+        S* dv = DIVSRC ? static_cast<S*>(batch.div[blockIdx.z]) : out;
+        a.dc = dv + cofs;
+        a.bd = __builtin_amdgcn_make_buffer_rsrc(dv, 0, field_bytes, 0x00020000);
+        a.div_scale = batch.div_scale;
         a.row_bytes = (unsigned)((size_t)pitch * sizeof(S));
         const unsigned col = (unsigned)((XOFF + 1 + NV * (ptrdiff_t)k) * (ptrdiff_t)sizeof(S));
         a.ld_off = ld_ok ? col : kBufOff;
@@ -918,11 +987,11 @@ __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbB
             else      tb_march<T, DIVMODE, false, false, S, NV>(t0, t1, a);
         }
     } else if (edge) {
-        if (wall) tb_march<T, DM, true, true, S, NV>(t0, t1, a);
-        else      tb_march<T, DM, true, false, S, NV>(t0, t1, a);
+        if (wall) tb_march<T, DM, true, true, S, NV, DIVSRC>(t0, t1, a);
+        else      tb_march<T, DM, true, false, S, NV, DIVSRC>(t0, t1, a);
     } else {
-        if (wall) tb_march<T, DM, false, true, S, NV>(t0, t1, a);
-        else      tb_march<T, DM, false, false, S, NV>(t0, t1, a);
+        if (wall) tb_march<T, DM, false, true, S, NV, DIVSRC>(t0, t1, a);
+        else      tb_march<T, DM, false, false, S, NV, DIVSRC>(t0, t1, a);
     }
 }
 
@@ -1163,13 +1232,6 @@ __global__ __launch_bounds__(256) void k_subtract_gradient(S* __restrict__ u, S*
 // back-trace of cell (i, j) needs u and v at (i, j) only -- the values this thread holds in registers
 // (as stored: rounded to the storage type first) -- so the advection need not read the two fields back.
 // Four cells per thread (64 apart, as in k_advect), per cell the arithmetic of k_subtract_gradient and k_advect.
-template <typename S>
-__device__ __forceinline__ float as_stored(float v)
-{
-    if constexpr (sizeof(S) == 2) return keep_f32((float)(S)keep_f32(v));
-    else return v;
-}
-
 template <typename S, typename IDX>
 __global__ __launch_bounds__(256) void k_gradient_advect(S* __restrict__ u, S* __restrict__ v, const S* __restrict__ p,
                                                          S* __restrict__ d, const S* __restrict__ d0, int pitch, int n,
@@ -1351,7 +1413,7 @@ void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void
 // divmode 0: beta; 2: beta unused, yd = RN64(1/beta); 4: beta = exact reciprocal of a power of two and alpha == 1;
 // 3: hi, lo = the two-term reciprocal where the tiles of |x0| minima allow it, yd elsewhere.
 void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const TbBatch& batch, int pitch, int n, int row_lo,
-                      int row_hi, int rb, int rb_edge)
+                      int row_hi, int rb, int rb_edge, bool divsrc)
 {
     const int rows = row_hi - row_lo;
     if (rows <= 0 || batch.count <= 0) return;
@@ -1381,7 +1443,14 @@ void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const T
     else if (divmode == 3) { FLUID_TB1(TT, 3); } \
     else if (divmode == 2) { FLUID_TB1(TT, 2); } \
     else { FLUID_TB1(TT, 0); }
-    if (T == 16) {                                       // 2-column lanes only (4-column ones would need > 256 registers)
+#define FLUID_TBD(TT) \
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_jacobi_tb<TT, 4, 2, S, true>), grid, block, 0, s, batch, pitch, n, row_lo, row_hi, rb, rb_edge, g))
+    if (divsrc) {                                        // first launch of a pressure solve, right-hand side computed from (u, v)
+        if (T == 16) { FLUID_TBD(16); }
+        else if (T == 12) { FLUID_TBD(12); }
+        else { FLUID_TBD(8); }
+    }
+    else if (T == 16) {                                  // 2-column lanes only (4-column ones would need > 256 registers)
         if (divmode == 4) { FLUID_TB2(16, 4, 2); }
         else if (divmode == 3) { FLUID_TB2(16, 3, 2); }
         else if (divmode == 2) { FLUID_TB2(16, 2, 2); }
@@ -1396,6 +1465,7 @@ void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const T
     else if (T == 8) { FLUID_TB(8) }
     else if (T == 4) { FLUID_TB(4) }
     else { FLUID_TB(2) }
+#undef FLUID_TBD
 #undef FLUID_TB
 #undef FLUID_TB1
 #undef FLUID_TB2

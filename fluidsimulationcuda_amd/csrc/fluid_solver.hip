@@ -553,7 +553,14 @@ struct Solve {
 // same launch.  Sweeps ping-pong between x's buffer and a scratch field's; if a
 // result ends in the scratch buffer the two fields trade buffers (pointer swap,
 // no copy) -- field ids, not addresses, are stable.
-int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int final_reach = 0)
+// `ds` (one GPU, a single pressure solve): the right-hand side sv[0].x0 is the divergence of (ds->u, ds->v), not yet
+// computed -- the first launch computes it row by row as it goes and stores it (fluid_kernels.hip, DIVSRC).
+struct DivSource {
+    int u, v;
+    float scale;          // -0.5f * h
+};
+
+int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int final_reach = 0, const DivSource* ds = nullptr)
 {
     static const int kScratch[3] = {FLUID_TMP0, FLUID_TMP1, FLUID_TMP2};
     if (iters < 0 || (iters & 1)) return fail(FLUID_E_INVALID, "sweep count must be even and >= 0 (got %d)", iters);
@@ -673,6 +680,14 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 }
                 bt.count = m;
                 bt.tile_pitch = fluid::tile_pitch(c->n);
+                const bool divsrc = ds != nullptr && k == 0;
+                if (divsrc) {
+                    bt.x[0] = c->f[ds->u];
+                    bt.x0[0] = c->f[ds->v];
+                    bt.div[0] = c->f[sv[0].x0];
+                    bt.div_scale = ds->scale;
+                    bt.x0_inc[0] = -0.0f;
+                }
                 int rb = c->tb_rows;
                 const int edge_pct = c->tb_edge_pct > 0 ? c->tb_edge_pct : 100;
                 auto edge_rows = [&](int r) { return std::max(2 * T, r * edge_pct / 100); };
@@ -702,13 +717,13 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 int trial = -1;
                 unsigned long long key = 0;
                 if (c->tb_rows <= 0 && c->autotune) {
-                    key = tune_key(c, T, m, divmode[first] == 4, hi - lo);
+                    key = tune_key(c, T, m + (divsrc ? 8 : 0), divmode[first] == 4, hi - lo);
                     rb = tune_pick(c, key, rb, T, hi - lo, &trial);
                 }
                 // edge windows (ghost columns) cost ~1.6x per row: shorter strips there keep the launch balanced
                 const int rb_edge = std::min(rb, edge_rows(rb));
                 if (trial >= 0) TRY(tune_begin(c, key, trial));
-                fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], c->tb_nv, bt, c->pitch, c->n, lo, hi, rb, rb_edge);
+                fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], c->tb_nv, bt, c->pitch, c->n, lo, hi, rb, rb_edge, divsrc);
                 if (trial >= 0) TRY(tune_end(c));
                 if (c->timing) {
                     c->launches += 1;
@@ -739,10 +754,10 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
     return timing_end(c, stop, iters * count);
 }
 
-int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int iters, int final_reach = 0)
+int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int iters, int final_reach = 0, const DivSource* ds = nullptr)
 {
     const Solve one{b, x, x0, alpha, beta};
-    return op_diffuse_batch(c, &one, 1, iters, final_reach);
+    return op_diffuse_batch(c, &one, 1, iters, final_reach, ds);
 }
 
 // FluidSequential.c:107-141.  The back-trace reaches dt0*max|vel| cells, so a
@@ -896,8 +911,38 @@ struct AdvectAfter {
     float dt;
 };
 
+// can the divergence be computed inside the first launch of the pressure solve that follows it?  One GPU, the fused
+// kernel with 2-column lanes, a first launch of at least 8 sweeps, the exact-reciprocal division of (alpha 1, beta 4)
+bool divergence_fuses(fluid_ctx* c, int iters)
+{
+    if (c->nranks != 1 || c->variant != fluid::JACOBI_TB || c->tb_nv != 2 || !c->fuse_divergence || iters < 8) return false;
+    const bool canonical = c->st == fluid::STORAGE_F16;
+    const long long cells = (long long)c->n * c->n;
+    if (cells < c->tb_min_cells) return false;
+    if (pick_sweeps(c, iters, iters, canonical, false, cells, true) < 8) return false;
+    return division_mode(c, 4.0f, 1.0f).mode == 4;
+}
+
 int project(fluid_ctx* c, int u, int v, int p, int div, int iters, const AdvectAfter* then_advect = nullptr)
 {
+    if (divergence_fuses(c, iters)) {
+        // computeDivergenceAndPressure (FluidSequential.c:143-158) inside the solve's first launch: p = 0 is a mark, the
+        // divergence is produced row by row as that launch's right-hand side and stored, ghost cells included
+        if (p == u || p == v || div == u || div == v || p == div)
+            return fail(FLUID_E_INVALID, "divergence: outputs must not alias inputs");
+        TRY(materialize(c, {u, v}));
+        mark_zero(c, p);
+        c->zero[div] = false;               // about to be overwritten entirely
+        c->pend[div] = false;
+        const DivSource ds{u, v, -0.5f * (1.0f / (float)c->n)};
+        c->in_pressure_solve = true;
+        const int rc = op_diffuse(c, 0, p, div, 1.0f, 4.0f, iters, /*final_reach=*/1, &ds);
+        c->in_pressure_solve = false;
+        TRY(rc);
+        wrote(c, div, 0);
+        if (then_advect) return op_gradient_advect(c, u, v, p, then_advect->b, then_advect->d, then_advect->d0, then_advect->dt);
+        return op_subtract_gradient(c, u, v, p);
+    }
     TRY(op_divergence(c, u, v, p, div, std::min(iters, c->halo - 1)));
     c->in_pressure_solve = true;            // timing only: reported separately (fluid_timing::pressure_ms)
     const int rc_solve = op_diffuse(c, 0, p, div, 1.0f, 4.0f, iters, /*final_reach=*/1);
@@ -1337,6 +1382,9 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
         return FLUID_OK;
     case FLUID_PARAM_TB_AUTOTUNE:
         c->autotune = value != 0;
+        return FLUID_OK;
+    case FLUID_PARAM_FUSE_DIVERGENCE:
+        c->fuse_divergence = value != 0;
         return FLUID_OK;
     case FLUID_PARAM_TB_T16_MIN_CELLS:
         if (value < -1) return fail(FLUID_E_INVALID, "TB_T16_MIN_CELLS must be >= 0, or -1 for the default rule");

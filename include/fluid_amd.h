@@ -72,6 +72,9 @@ enum {
     ,FLUID_PARAM_TB_AUTOTUNE = 8   /* 1 (default): with TB_ROWS = 0 the strip height of each launch shape is measured
                                       at run time -- the first ~20 launches of a shape try a handful of heights, the
                                       fastest is kept for the process; 0: the closed-form choice.  Speed only.  */
+    ,FLUID_PARAM_FUSE_DIVERGENCE = 9 /* 1 (default): inside fluid_step / fluid_vel_step on one GPU the divergence of a
+                                      projection is computed by the first launch of the pressure solve that consumes it
+                                      (no separate pass over u, v); 0: its own kernel first.  Speed only.        */
     ,FLUID_PARAM_TB_MIN_CELLS = 4  /* FLUID_JACOBI_TB fuses sweeps only on slabs of at least this many cells
                                       (default 0: always); smaller ones run one-thread-per-cell sweeps   */
 };

@@ -40,6 +40,34 @@ def test_golden_steps(F, n, iters, steps, variant):
                     assert_bit_equal(got, want, "%s after step %d, n=%d" % (name, z, n))
 
 
+@pytest.mark.parametrize("max_t", [16, 12, 8])
+@pytest.mark.parametrize("n", [1, 2, 3, 14, 61, 95, 96, 97, 126, 193, 257, 300, 1022])
+def test_divergence_inside_the_pressure_solve_matches_oracle(F, oracle, n, max_t):
+    """On one GPU a projection's divergence (FluidSequential.c:143-158) is computed by the first launch of the
+    pressure solve that consumes it, row by row, and stored with its ghost cells (it is the step's v_prev).  Window
+    and wall edge sizes, every first-launch depth, strip heights that put ghost rows in their own strips; u, v
+    with both zeros and exact cancellations; against the oracle, all six fields."""
+    from fluidsimulationcuda_amd import capi
+    rng = np.random.default_rng(n * 31 + max_t)
+    vals = np.array([-1, -0.5, -0.25, 0.0, -0.0, 0.25, 0.5, 1], np.float32)
+    for rows, coarse in ((0, False), (3, True), (40, False)):
+        fields = [rng.choice(vals, size=(n + 2, n + 2)).astype(np.float32) if coarse else rnd(rng, n) for _ in range(6)]
+        u, v, dens, u0, v0, d0 = fields
+        params = {capi.PARAM_TB_MIN_CELLS: 0, capi.PARAM_TB_T16_MIN_CELLS: 0, capi.PARAM_TB_MAX_SWEEPS: max_t,
+                  capi.PARAM_TB_ROWS: rows}
+        with F.FluidSolver(n, params=params) as s:
+            s.upload(u=u, v=v, dens=dens, u_prev=u0, v_prev=v0, dens_prev=d0)
+            s.timing_enable(True)
+            s.step(1, use_sources=True)
+            s.vel_step()
+            t = s.timing_read()
+            assert t["divergence_calls"] == 0, "the divergence was meant to ride in the pressure solves"
+            oracle.step_src(u, v, dens, u0, v0, d0)
+            oracle.vel_step(u, v, u0, v0)
+            for name, want in (("u", u), ("v", v), ("dens", dens), ("u_prev", u0), ("v_prev", v0), ("dens_prev", d0)):
+                assert_bit_equal(s.download(name), want, "%s n=%d maxT=%d rows=%d" % (name, n, max_t, rows))
+
+
 def test_multi_step_call_equals_single_steps(F):
     g = load_golden("step_n61_k40.npz")
     z0 = np.zeros((63, 63), np.float32)

@@ -112,7 +112,8 @@ def test_timing_categories_count_every_operator():
     import fluidsimulationcuda_amd as F
     from fluidsimulationcuda_amd.harness import initialize_parameters, run_steps
     n = 254
-    with F.FluidSolver(n) as s:
+    from fluidsimulationcuda_amd import capi
+    with F.FluidSolver(n, params={capi.PARAM_FUSE_DIVERGENCE: 0}) as s:     # every operator as a launch of its own
         s.upload(**initialize_parameters(n))
         s.timing_enable(True)
         s.step(1, use_sources=True)
@@ -129,6 +130,13 @@ def test_timing_categories_count_every_operator():
         s.timing_enable(False)
         r = run_steps(s, 3, first_uses_sources=False)
         assert r["sweeps"] == 600 and 0 < r["Diffusion"] < r["Tot"]
+    with F.FluidSolver(n) as s:          # default: the divergence is computed inside the pressure solve's first launch
+        s.upload(**initialize_parameters(n))
+        s.timing_enable(True)
+        s.step(1, use_sources=True)
+        s.step(2)
+        t = s.timing_read()
+        assert (t["divergence_calls"], t["solves"], t["sweeps"], t["projection_calls"]) == (0, 9, 600, 6)
 
 
 @pytest.mark.gpu
