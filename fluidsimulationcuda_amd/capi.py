@@ -90,6 +90,7 @@ SIGNATURES = {
     "fluid_set_jacobi_variant": [_ctx, _i],
     "fluid_division_mode": [_ctx, _f, _f, C.POINTER(_i)],
     "fluid_autotune_pending": [_ctx, C.POINTER(_i)],
+    "fluid_plan_sweeps": [_i, _i, _i, _i, _i, _i, _i, C.POINTER(_i), _i, C.POINTER(_i)],
     "fluid_set_param": [_ctx, _i, _i],
     "fluid_timing_enable": [_ctx, _i],
     "fluid_timing_read": [_ctx, C.POINTER(Timing), _i],

@@ -1403,6 +1403,32 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
     }
 }
 
+int fluid_plan_sweeps(int N, int rows, int storage, int pressure_form, int iters, int max_sweeps, int t16_min_cells, int* depths,
+                      int capacity, int* count)
+{
+    if (N < 1 || N > kMaxN || rows < 1 || rows > N || iters < 0 || (iters & 1) || !depths || !count || capacity < 0)
+        return fail(FLUID_E_INVALID, "fluid_plan_sweeps: bad argument");
+    if (storage != FLUID_STORAGE_F32 && storage != FLUID_STORAGE_F16) return fail(FLUID_E_INVALID, "unknown storage type %d", storage);
+    if (max_sweeps != 16 && max_sweeps != 12 && max_sweeps != 8 && max_sweeps != 4 && max_sweeps != 2)
+        return fail(FLUID_E_INVALID, "max_sweeps must be 16, 12, 8, 4 or 2");
+    fluid_ctx c;                            // host-side description only: no device, no stream
+    c.n = N;
+    c.st = storage;
+    c.esz = fluid::storage_bytes(storage);
+    c.field_bytes = (size_t)(N + 2) * fluid::pitch_for(N) * c.esz;
+    c.tb_max_t = max_sweeps;
+    c.tb_t16_min_cells = t16_min_cells;
+    int k = 0;
+    for (int left = iters; left > 0;) {
+        const int t = pick_sweeps(&c, left, left, storage == FLUID_STORAGE_F16, false, (long long)rows * N, pressure_form != 0);
+        if (k < capacity) depths[k] = t;
+        ++k;
+        left -= t;
+    }
+    *count = k;
+    return FLUID_OK;
+}
+
 int fluid_autotune_pending(fluid_ctx* c, int* shapes_open)
 {
     TRY(check_ctx(c));

@@ -183,6 +183,11 @@ int fluid_set_jacobi_variant(fluid_ctx *ctx, int variant);
  * if this beta has not been seen): 0 true division, 2 double-precision reciprocal, 3 two-term float reciprocal
  * where the right-hand side allows it (else as 2), 4 exact float reciprocal (beta a power of two, alpha 1). */
 int fluid_division_mode(fluid_ctx *ctx, float alpha, float beta, int *mode);
+/* The launch depths FLUID_JACOBI_TB uses for one solve of `iters` sweeps on a grid (or slab) of `rows` x N cells: host
+ * logic only (no device needed) -- `pressure_form`: alpha 1 / beta 4; `max_sweeps`, `t16_min_cells` as the parameters of the
+ * same names (-1: default rule).  Writes up to `capacity` depths and the number of launches. */
+int fluid_plan_sweeps(int N, int rows, int storage, int pressure_form, int iters, int max_sweeps, int t16_min_cells,
+                      int *depths, int capacity, int *count);
 /* Launch shapes whose strip height is still being measured (FLUID_PARAM_TB_AUTOTUNE), process-wide: a benchmark runs
  * untimed steps until this reaches 0. */
 int fluid_autotune_pending(fluid_ctx *ctx, int *shapes_open);

@@ -82,3 +82,36 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
+
+
+def test_planned_launch_depths_without_gpu():
+    """fluid_plan_sweeps: the host logic that decides how many sweeps each launch of a solve fuses (pick_sweeps in
+    fluid_solver.hip) needs no device.  Against conftest.tb_schedule (the mirror the GPU tests assert launch counts
+    with) and against the size rules: deep launches from 8 M cells, 16 for the general form only once a field
+    outgrows 96 MiB and never on slabs under 3000 rows, fp16 storage always the greedy 8 / 4 / 2."""
+    import ctypes as C
+    from conftest import tb_schedule
+    from fluidsimulationcuda_amd import capi
+    L = capi.lib()
+
+    def plan(n, rows, storage, pressure, iters, max_t=16, t16=-1):
+        buf, cnt = (C.c_int * 64)(), C.c_int()
+        assert L.fluid_plan_sweeps(n, rows, storage, pressure, iters, max_t, t16, buf, 64, C.byref(cnt)) == capi.OK
+        return list(buf[:cnt.value])
+
+    for iters in (0, 2, 6, 8, 12, 20, 22, 28, 32, 40, 48, 100):
+        for max_t in (16, 12, 8, 4, 2):
+            assert plan(300, 300, 0, 1, iters, max_t, 0) == tb_schedule(iters, max_t), (iters, max_t)
+            assert sum(plan(300, 300, 0, 0, iters, max_t, 0)) == iters
+    assert plan(4094, 4094, 0, 1, 40) == [16, 12, 12]            # BASELINE config 2: pressure form at 4096^2
+    assert plan(4094, 4094, 0, 0, 40) == [12, 12, 8, 8]          # general form: fields still inside the Infinity Cache
+    assert plan(8190, 8190, 0, 0, 40) == [16, 12, 12]            # 8192^2: both forms
+    assert plan(8190, 2047, 0, 1, 40) == [12, 12, 8, 8]          # one slab of four: 16 M cells, but too few rows for 16
+    assert plan(8190, 1023, 0, 1, 40) == [8, 8, 8, 8, 8]         # one slab of eight: just under 8 M cells
+    assert plan(1022, 1022, 0, 1, 40) == [8, 8, 8, 8, 8]         # small grids: 8 at a time
+    assert plan(16382, 16382, 1, 1, 40) == [8, 8, 8, 8, 8]       # fp16 storage: the schedule is part of the result
+    assert plan(16382, 16382, 1, 0, 20) == [8, 8, 4]
+    buf, cnt = (C.c_int * 2)(), C.c_int()
+    assert L.fluid_plan_sweeps(300, 300, 0, 1, 40, 8, -1, buf, 2, C.byref(cnt)) == capi.OK and cnt.value == 5   # reports the count past capacity
+    assert L.fluid_plan_sweeps(300, 300, 0, 1, 7, 8, -1, buf, 2, C.byref(cnt)) == capi.E_INVALID               # odd sweep count
+    assert L.fluid_plan_sweeps(300, 301, 0, 1, 8, 8, -1, buf, 2, C.byref(cnt)) == capi.E_INVALID
