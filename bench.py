@@ -69,7 +69,7 @@ def parse():
                          "(BASELINE config 4: fp16 fields, fp32 arithmetic)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the measured path) or gloo (host-staged rehearsal "
                                                       "of the multi-process path when ranks outnumber GPUs)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "torch"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rccl", "torch", "try-rccl"],
                     help="multi-GPU halo exchange: the library's own RCCL exchange (C++, no host wait) or "
                          "torch.distributed (auto: rccl with --backend nccl)")
     ap.add_argument("--check", action="store_true", help="multi-GPU: also verify bit equality with a 1-context run (small grids)")
@@ -258,7 +258,8 @@ def main():
     grid = a.grid or (4096 if world == 1 else 8192)
     n = grid - 2
     cells = grid * grid
-    exchange = a.exchange if a.exchange != "auto" else ("rccl" if a.backend == "nccl" else "torch")
+    # auto: the library's own RCCL exchange when every rank brings it up, else torch.distributed (SlabSolver agrees on it)
+    exchange = {"auto": "auto" if a.backend == "nccl" else "torch", "try-rccl": "auto"}.get(a.exchange, a.exchange)
 
     def make(n_, fuse_divergence=True):
         s = SlabSolver(n_, rank=rank, nranks=world, halo=a.halo, jacobi=a.variant,
@@ -276,6 +277,7 @@ def main():
         return s
 
     tuning = {}
+    native = [False]
 
     def tune(n_):
         """The library measures the fused kernel's strip heights during the first launches of each launch shape
@@ -307,6 +309,7 @@ def main():
         out = measure(s, dist, world, steps, warmup, a.iters)
         solve = pressure_solve_rate(s, a.iters, max(steps // 2, 4)) if world == 1 else None
         calls = s.exchange_calls()
+        native[0] = s.native_exchange
         s.close()
         return out + (solve,), fields, calls
 
@@ -359,6 +362,7 @@ def main():
     (elapsed, jac_ms, prs_ms, t, solve), fields, calls = run(n, a.steps, a.warmup)
     r = rates(elapsed, jac_ms, prs_ms, t, a.steps, cells, solve)
     ms_step, t_sweep = r["ms_per_step"], r["t_sweep"]
+    native_exchange = native[0]
     sweeps, field_launches = t["sweeps"], t["jacobi_field_launches"]
     bpc = BYTES_PER_CELL_SWEEP // (2 if a.dtype == "f16" else 1)
     achieved = bpc * cells / t_sweep / 1e9
@@ -378,8 +382,8 @@ def main():
                                % (grid, grid, a.iters, arith),
                    "grid": grid, "iters": a.iters, "jacobi_kernel": KERNELS[a.variant],
                    "parallelism": "1 GPU" if world == 1 else "row slabs x%d, halo rows by %s" % (
-                       world, ("RCCL, library-native exchange" if exchange == "rccl" else "RCCL via torch.distributed")
-                       if a.backend == "nccl" else a.backend + " (host-staged rehearsal)")},
+                       world, "RCCL, library-native exchange (csrc/fluid_exchange_rccl.hip)" if native_exchange else
+                       "RCCL via torch.distributed" if a.backend == "nccl" else a.backend + " (host-staged rehearsal)")},
         "ms_per_sim_step": ms_step,
         "kernel_ms_per_step": dict(r["kernel_ms_per_step"], note="HIP events per operator category (the reference's timers, "
                                    "FluidSequential.c:192-234); 'projection' holds the gradient subtractions, the second "

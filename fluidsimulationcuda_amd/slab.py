@@ -185,21 +185,43 @@ class SlabSolver(FluidSolver):
                        for k in range(capi.NFIELDS)]
         self.exchange = None
         self.native_exchange = False
-        if nranks > 1 and exchange == "rccl":
+        if nranks > 1 and exchange in ("rccl", "auto"):
+            # "auto": the library's own exchange if it comes up on EVERY rank (agreed by an all-reduce, so that no rank
+            # is left on a different transport), else the torch.distributed one
             import ctypes as C
             on_dev = dist.get_backend(group) == "nccl"
-            uid = torch.zeros(capi.RCCL_ID_BYTES, dtype=torch.uint8, device=self.device if on_dev else "cpu")
+            where = self.device if on_dev else "cpu"
+            uid = torch.zeros(capi.RCCL_ID_BYTES, dtype=torch.uint8, device=where)
+            ok = 1
             if rank == 0:
                 buf = (C.c_ubyte * capi.RCCL_ID_BYTES)()
-                capi.check(L.fluid_rccl_unique_id(buf, capi.RCCL_ID_BYTES))
-                uid.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+                rc = L.fluid_rccl_unique_id(buf, capi.RCCL_ID_BYTES)
+                if rc == capi.OK:
+                    uid.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+                elif exchange == "rccl":
+                    capi.check(rc)
+                else:
+                    ok = 0
             src = dist.get_global_rank(group, 0) if group is not None else 0
             dist.broadcast(uid, src=src, group=group)
             raw = bytes(uid.cpu().numpy().tobytes())
-            with torch.cuda.device(self.device):
-                capi.check(L.fluid_exchange_rccl_attach(self._h, raw, len(raw)))
-            self.native_exchange = True
-        elif nranks > 1:
+            if any(raw):
+                with torch.cuda.device(self.device):
+                    rc = L.fluid_exchange_rccl_attach(self._h, raw, len(raw))
+                if rc != capi.OK:
+                    if exchange == "rccl":
+                        capi.check(rc)
+                    ok = 0
+            else:
+                ok = 0
+            agreed = torch.tensor([ok], dtype=torch.int32, device=where)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=group)
+            if int(agreed.item()) == 1:
+                self.native_exchange = True
+            else:
+                capi.check(L.fluid_exchange_rccl_detach(self._h))
+                exchange = "torch"
+        if nranks > 1 and not self.native_exchange:
             if dist.get_backend(group) == "nccl":
                 # batched send/recv must not be the first operation on a NCCL group: start with an all-reduce
                 hello = torch.ones(1, device=self.device)
