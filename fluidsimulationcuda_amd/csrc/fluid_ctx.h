@@ -38,6 +38,9 @@ struct fluid_ctx {
     size_t esz = 4;                       // bytes per stored element
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t stream2 = nullptr;        // slabs: the density diffusion runs beside the velocity path (full_step)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool slab_overlap = true;
     void* f[FLUID_NFIELDS] = {};
     size_t field_bytes = 0;
     unsigned int* d_scalar = nullptr;     // device word for the reductions

@@ -118,6 +118,7 @@ int timing_collect(fluid_ctx* c)
 {
     if (c->ev_used == 0) return FLUID_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
     for (size_t k = 0; k < c->ev_used; ++k) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k].a, c->ev_pool[k].b));
@@ -560,9 +561,12 @@ struct DivSource {
     float scale;          // -0.5f * h
 };
 
-int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int final_reach = 0, const DivSource* ds = nullptr)
+int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int final_reach = 0, const DivSource* ds = nullptr,
+                     int scratch_base = 0)
 {
-    static const int kScratch[3] = {FLUID_TMP0, FLUID_TMP1, FLUID_TMP2};
+    static const int kScratchAll[3] = {FLUID_TMP0, FLUID_TMP1, FLUID_TMP2};
+    if (scratch_base < 0 || scratch_base + count > 3) return fail(FLUID_E_INVALID, "a batch holds 1 to 3 solves");
+    const int* kScratch = kScratchAll + scratch_base;      // (a solve that runs beside another batch on a second stream takes the last one)
     if (iters < 0 || (iters & 1)) return fail(FLUID_E_INVALID, "sweep count must be even and >= 0 (got %d)", iters);
     if (count < 1 || count > 3) return fail(FLUID_E_INVALID, "a batch holds 1 to 3 solves");
     for (int k = 0; k < count; ++k) {
@@ -733,6 +737,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
             }
         }
         r = multi ? std::min(r - T, exchange_cap(c)) : kEverywhere;
+        if (ds && k == 0 && multi) c->reach[sv[0].x0] = std::max(0, std::min(c->reach[sv[0].x0], r));   // the divergence exists where this launch stored it
         for (int j = 0; j < count; ++j) {
             c->zero[cur[j]] = false;       // from now on this buffer is just the other half of the ping-pong
             c->zero[nxt[j]] = false;
@@ -913,27 +918,32 @@ struct AdvectAfter {
 
 // can the divergence be computed inside the first launch of the pressure solve that follows it?  One GPU, the fused
 // kernel with 2-column lanes, a first launch of at least 8 sweeps, the exact-reciprocal division of (alpha 1, beta 4)
-bool divergence_fuses(fluid_ctx* c, int iters)
+bool divergence_fuses(fluid_ctx* c, int iters, int reach)
 {
-    if (c->nranks != 1 || c->variant != fluid::JACOBI_TB || c->tb_nv != 2 || !c->fuse_divergence || iters < 8) return false;
+    if (c->variant != fluid::JACOBI_TB || c->tb_nv != 2 || !c->fuse_divergence || iters < 8) return false;
     const bool canonical = c->st == fluid::STORAGE_F16;
-    const long long cells = (long long)c->n * c->n;
-    if (cells < c->tb_min_cells) return false;
-    if (pick_sweeps(c, iters, iters, canonical, false, cells, true) < 8) return false;
+    const long long slab_cells = (long long)(c->nranks > 1 ? c->min_slab : c->n) * c->n;
+    if ((canonical ? (long long)c->n * c->n : slab_cells) < c->tb_min_cells) return false;
+    const int room = c->nranks > 1 ? std::min(reach + 1, iters) : iters;        // sweeps the first launch may fuse (op_diffuse_batch)
+    if (room < 8 || pick_sweeps(c, iters, room, canonical, false, slab_cells, true) < 8) return false;
     return division_mode(c, 4.0f, 1.0f).mode == 4;
 }
 
 int project(fluid_ctx* c, int u, int v, int p, int div, int iters, const AdvectAfter* then_advect = nullptr)
 {
-    if (divergence_fuses(c, iters)) {
+    // rows past the slab on which the divergence is wanted (so that the solve needs no exchange of its own), as op_divergence
+    const int reach = c->nranks > 1 ? std::max(0, std::min(std::min(iters, c->halo - 1), exchange_cap(c) - 1)) : 0;
+    if (divergence_fuses(c, iters, reach)) {
         // computeDivergenceAndPressure (FluidSequential.c:143-158) inside the solve's first launch: p = 0 is a mark, the
         // divergence is produced row by row as that launch's right-hand side and stored, ghost cells included
         if (p == u || p == v || div == u || div == v || p == div)
             return fail(FLUID_E_INVALID, "divergence: outputs must not alias inputs");
         TRY(materialize(c, {u, v}));
+        if (c->nranks > 1) TRY(need(c, {u, v}, reach + 1));
         mark_zero(c, p);
         c->zero[div] = false;               // about to be overwritten entirely
         c->pend[div] = false;
+        c->reach[div] = c->nranks > 1 ? reach : kEverywhere;   // what the first launch can form from (u, v); it records what it stored
         const DivSource ds{u, v, -0.5f * (1.0f / (float)c->n)};
         c->in_pressure_solve = true;
         const int rc = op_diffuse(c, 0, p, div, 1.0f, 4.0f, iters, /*final_reach=*/1, &ds);
@@ -1035,6 +1045,32 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
                 launches.pop_back();
             }
         if (fill1 == 0) std::swap(fill1, fill2);
+    }
+    if (c->stream2 && c->slab_overlap && std::min(iters, c->halo) >= iters) {
+        // A slab is a small problem: its launches leave most of the chip idle (one rank's share of 8192^2 / 8 keeps a
+        // quarter of the wave slots busy), and the density diffusion depends on nothing in the velocity path.  So it
+        // runs beside that path on a second stream -- from the moment its rows have arrived until the density advect at
+        // the end -- and also fills the two stretches in which the host waits for the advect bounds.  Only when the ghost
+        // zones cover the whole solve: an exchange inside it would put collectives on two streams in an order the ranks
+        // could not agree on.  It ping-pongs with TMP2, the velocity path with TMP0 / TMP1.
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        hipStream_t main_stream = c->stream;
+        c->stream = c->stream2;
+        const int rc_dens = op_diffuse_batch(c, all + 2, 1, iters, 0, nullptr, /*scratch_base=*/2);
+        hipError_t e_join = rc_dens == FLUID_OK ? hipEventRecord(c->ev_join, c->stream2) : hipSuccess;
+        c->stream = main_stream;
+        TRY(rc_dens);
+        HIP_TRY(e_join);
+        TRY(op_diffuse_batch(c, all, 2, iters));
+        TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
+        TRY(advect_prepare(c, {U0, V0}, U0, V0, dt0));
+        TRY(op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt));
+        TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters));
+        TRY(vmax_begin(c, U, V));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        TRY(advect_halo(c, {D0}, dt0));
+        return op_advect(c, 0, D, D0, U, V, dt);
     }
     const int rest = fill1 + fill2, head = iters - rest;
     if (head > 0) TRY(op_diffuse_batch(c, all, 3, head));
@@ -1215,6 +1251,11 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             c->num_cu = cus;
     }
+    if (P > 1) {
+        if (!hip_ok(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), "hipStreamCreate(second stream)")) return bail(rc);
+        if (!hip_ok(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate")) return bail(rc);
+        if (!hip_ok(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreate")) return bail(rc);
+    }
     if (!hip_ok(hipMemsetAsync(c->arena, 0, bytes, c->stream), "hipMemsetAsync(arena)")) return bail(rc);
     c->d_scalar = reinterpret_cast<unsigned int*>(c->arena + c->field_bytes * FLUID_NFIELDS);   // RCCL-addressable
     {
@@ -1243,6 +1284,7 @@ int fluid_destroy(fluid_ctx* c)
 {
     if (!c) return FLUID_OK;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (auto& p : c->ev_pool) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -1264,6 +1306,9 @@ int fluid_destroy(fluid_ctx* c)
     if (c->tiles) (void)hipFree(c->tiles);
     if (c->scalar_ready) (void)hipEventDestroy(c->scalar_ready);
     if (c->own_arena && c->arena) (void)hipFree(c->arena);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (g_cached == c) g_cached = nullptr;
     delete c;
@@ -1382,6 +1427,9 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
         return FLUID_OK;
     case FLUID_PARAM_TB_AUTOTUNE:
         c->autotune = value != 0;
+        return FLUID_OK;
+    case FLUID_PARAM_SLAB_OVERLAP:
+        c->slab_overlap = value != 0;
         return FLUID_OK;
     case FLUID_PARAM_FUSE_DIVERGENCE:
         c->fuse_divergence = value != 0;

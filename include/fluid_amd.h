@@ -72,6 +72,9 @@ enum {
     ,FLUID_PARAM_TB_AUTOTUNE = 8   /* 1 (default): with TB_ROWS = 0 the strip height of each launch shape is measured
                                       at run time -- the first ~20 launches of a shape try a handful of heights, the
                                       fastest is kept for the process; 0: the closed-form choice.  Speed only.  */
+    ,FLUID_PARAM_SLAB_OVERLAP = 10 /* 1 (default): on row slabs fluid_step runs the density diffusion on a second stream
+                                      beside the velocity path (a slab's launches leave most of the chip idle), when the
+                                      ghost zones cover a whole solve; 0: one stream.  Speed only.                */
     ,FLUID_PARAM_FUSE_DIVERGENCE = 9 /* 1 (default): inside fluid_step / fluid_vel_step on one GPU the divergence of a
                                       projection is computed by the first launch of the pressure solve that consumes it
                                       (no separate pass over u, v); 0: its own kernel first.  Speed only.        */
