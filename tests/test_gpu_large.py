@@ -138,3 +138,28 @@ def test_fp16_fused_launches_at_16384_match_rounded_oracle(F, oracle):
     del x, x0
     assert_bit_equal(got, want, "fp16 storage, 8 + 8 sweeps at 16384^2")
     assert_bit_equal(got, h(got), "stored values are fp16")
+
+
+def test_fp16_two_slabs_at_16384_match_one_context(F):
+    """BASELINE config 4 as it is meant to run -- 16384^2, fp16 storage, row slabs: two slabs (in-process fabric, one
+    GPU) against one context, two steps, every bit of u, v and dens.  (With fp16 storage every launch rounds once, so
+    this also pins that slabs and one GPU take the same launch schedule at this size; the one-context arithmetic is
+    pinned to the rounded oracle above and in test_gpu_f16.py.)"""
+    from test_gpu_slab import run_ranks
+    from fluidsimulationcuda_amd import capi
+    from fluidsimulationcuda_amd.harness import initialize_parameters
+    n = 16382
+    f = initialize_parameters(n, seed=4)
+
+    def body(s):
+        s.step(1, use_sources=True)
+        s.step(1)
+
+    with F.FluidSolver(n, storage=capi.STORAGE_F16) as s:
+        s.upload(**f)
+        body(s)
+        one = {k: s.download(k) for k in ("u", "v", "dens")}
+    got, fab = run_ranks(n, 2, 0, f, body, jacobi=3, storage=capi.STORAGE_F16)
+    assert fab.log[1] == fab.log[0]
+    for k in ("u", "v", "dens"):
+        assert_bit_equal(got[k], one[k], "%s: 2 slabs vs one context at 16384^2, fp16 storage" % k)
