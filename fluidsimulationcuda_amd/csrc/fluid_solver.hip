@@ -602,12 +602,14 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         for (int k = 0; k < count; ++k)
             if (divmode[k] == 3) {
                 tb.field[m] = c->f[sv[k].x0];
-                tb.tiles[m] = c->tiles + (size_t)k * tile_words;
+                tb.tiles[m] = c->tiles + (size_t)(scratch_base + k) * tile_words;      // a solve's tiles go with its scratch field: a
+                                                                                        // batch on the second stream has slots of its own
                 valid = std::min(valid, c->nranks > 1 ? c->reach[sv[k].x0] : kEverywhere);
                 ++m;
             }
         if (m > 0) {
-            if (c->nranks > 1) HIP_TRY(hipMemsetAsync(c->tiles, 0, 3 * tile_words * sizeof(unsigned), c->stream));
+            if (c->nranks > 1)
+                HIP_TRY(hipMemsetAsync(c->tiles + (size_t)scratch_base * tile_words, 0, (size_t)count * tile_words * sizeof(unsigned), c->stream));
             int lo, hi;
             rows(c, std::min(valid, c->n), &lo, &hi);
             fluid::launch_tile_min_abs(c->stream, c->st, tb, m, c->pitch, c->n, lo, hi, fluid::tile_pitch(c->n));
@@ -675,7 +677,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                     bt.yd[m] = plan[j].yd;
                     bt.hi[m] = plan[j].hi;
                     bt.lo[m] = plan[j].lo;
-                    bt.tiles[m] = divmode[j] == 3 ? c->tiles + (size_t)j * tile_words : nullptr;
+                    bt.tiles[m] = divmode[j] == 3 ? c->tiles + (size_t)(scratch_base + j) * tile_words : nullptr;
                     bt.tile_thr[m] = plan[j].tile_thr;
                     bt.b[m] = sv[j].b;
                     bt.x_zero[m] = c->zero[cur[j]] ? 1 : 0;
