@@ -34,17 +34,24 @@ struct RcclApi {
     std::string error;
 };
 
-// the process's RCCL: one already loaded if there is one, else $FLUID_RCCL_LIB, else the system's
+// the process's RCCL
 static RcclApi* rccl_api()
 {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
+        // $FLUID_RCCL_LIB wins (a site's own build; the tests' thread-ranks stand-in); else a copy the process already holds;
+        // else the system's
+        if (const char* env = std::getenv("FLUID_RCCL_LIB")) {
+            api.handle = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+            if (!api.handle) {
+                api.error = std::string("cannot load $FLUID_RCCL_LIB: ") + (dlerror() ? dlerror() : env);
+                return;
+            }
+        }
         const char* names[] = {"librccl.so", "librccl.so.1"};
         for (const char* nm : names)
             if (!api.handle) api.handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-        if (!api.handle)
-            if (const char* env = std::getenv("FLUID_RCCL_LIB")) api.handle = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
         const char* fallbacks[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* nm : fallbacks)
             if (!api.handle) api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);

@@ -257,7 +257,7 @@ int fluid_exchange_now(fluid_ctx *ctx, int kind, const int *fields, int nfields,
  * naivePar/FluidParallelBlockPerElement-Naive.cu:351-355 only ever selects device 0).  Halo rows travel as grouped
  * ncclSend/ncclRecv between neighbouring slabs, the advect fall-back as grouped ncclBroadcast, the velocity bound
  * as an in-place ncclAllReduce(max) on the device scalar; everything is enqueued on the context's stream.
- * librccl is bound at run time (an RCCL the process already holds is reused; else $FLUID_RCCL_LIB; else the
+ * librccl is bound at run time ($FLUID_RCCL_LIB if set; else an RCCL the process already holds; else the
  * system's), so single-GPU users need none.
  *   fluid_rccl_unique_id():       one rank calls it and hands the FLUID_RCCL_ID_BYTES bytes to all others (any way)
  *   fluid_exchange_rccl_attach(): every rank, with its context (rank / nranks from fluid_create_ex) and that id, on
