@@ -217,6 +217,14 @@ class SlabSolver(FluidSolver):
             agreed = torch.tensor([ok], dtype=torch.int32, device=where)
             dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=group)
             if int(agreed.item()) == 1:
+                # one real exchange before anything depends on it: every rank marks a scratch field with its number,
+                # two halo rows travel each way, and each rank checks whose rows arrived
+                ok = self._native_exchange_selftest()
+                agreed = torch.tensor([ok], dtype=torch.int32, device=where)
+                dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=group)
+                if int(agreed.item()) != 1 and exchange == "rccl":
+                    raise RuntimeError("the library's RCCL exchange delivered the wrong rows in its self-test")
+            if int(agreed.item()) == 1:
                 self.native_exchange = True
             else:
                 capi.check(L.fluid_exchange_rccl_detach(self._h))
@@ -231,6 +239,25 @@ class SlabSolver(FluidSolver):
             off = self.scalar_ptr() - self.arena.data_ptr()
             self.exchange.set_scalar(self.arena[off:off + 4].view(torch.int32))
             self.set_exchange(self.exchange)
+
+    def _native_exchange_selftest(self):
+        import ctypes as C
+        lo, hi = self.owned_rows
+        depth = min(2, hi - lo)
+        self.fill("tmp2", float(self.rank + 1))
+        ids = (C.c_int * 1)(capi.TMP2)
+        if capi.lib().fluid_exchange_now(self._h, capi.XCHG_HALO, ids, 1, depth) != capi.OK:
+            return 0
+        self.synchronize()
+        rows = self.field_tensor(capi.TMP2)
+        ok = True
+        if self.rank > 0:
+            ok &= bool((rows[lo - depth:lo, self.xoff:self.xoff + self.n + 2] == float(self.rank)).all())
+        if self.rank < self.nranks - 1:
+            ok &= bool((rows[hi:hi + depth, self.xoff:self.xoff + self.n + 2] == float(self.rank + 2)).all())
+        ok &= bool((rows[lo:hi, self.xoff:self.xoff + self.n + 2] == float(self.rank + 1)).all())
+        self.fill("tmp2", 0.0)
+        return 1 if ok else 0
 
     def field_tensor(self, fid):
         """[n+2, pitch] view of the buffer field `fid` occupies right now."""

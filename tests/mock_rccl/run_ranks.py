@@ -49,6 +49,7 @@ def work(r):
     try:
         s = solvers[r]
         capi.check(L.fluid_exchange_rccl_attach(s._h, uid, capi.RCCL_ID_BYTES))     # blocks until every rank has joined
+        assert s._native_exchange_selftest() == 1, "rows of the attach-time self-test arrived wrong"   # what SlabSolver runs
         s.load_global(**fields)
         body(s)
         calls = s.exchange_calls()                                                    # of the steps alone
