@@ -44,6 +44,7 @@ struct fluid_ctx {
     void* f[FLUID_NFIELDS] = {};
     size_t field_bytes = 0;
     unsigned int* d_scalar = nullptr;     // device word for the reductions
+    float* d_partials = nullptr;          // slabs: per-block maxima of the gradient subtraction (launch_subtract_gradient)
     unsigned int* tiles = nullptr;        // 3 x tile_rows x tile_pitch words: |x0| minima per tile for division mode 3
     unsigned int* h_scalar = nullptr;     // pinned host mirror
     hipEvent_t scalar_ready = nullptr;    // recorded behind the scalar's device-to-host copy

@@ -59,8 +59,11 @@ void launch_advect2(hipStream_t s, int st, void* da, const void* d0a, int ba, vo
                     const void* v, int pitch, int n, int row_lo, int row_hi, float dt0);
 void launch_divergence(hipStream_t s, int st, const void* u, const void* v, void* p, void* div, int pitch, int n,
                        int row_lo, int row_hi, float h, int write_p);
+// max_out != nullptr: also leaves max(|u|, |v|) of the stored interior values in *max_out (the bit pattern of a
+// non-negative float; what launch_absmax2 would produce for the same rows), via `partials` (kMaxPartials floats of scratch)
+constexpr int kMaxPartials = 8192;
 void launch_subtract_gradient(hipStream_t s, int st, void* u, void* v, const void* p, int pitch, int n, int row_lo,
-                              int row_hi, float h);
+                              int row_hi, float h, float* partials = nullptr, unsigned int* max_out = nullptr);
 void launch_gradient_advect(hipStream_t s, int st, void* u, void* v, const void* p, void* d, const void* d0, int pitch, int n,
                             int row_lo, int row_hi, float h, float dt0, int b);
 void launch_absmax2(hipStream_t s, int st, const void* u, const void* v, int pitch, int n, int row_lo, int row_hi,

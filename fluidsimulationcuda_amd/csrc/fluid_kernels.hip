@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "fluid_kernels.h"
 
 namespace fluid {
@@ -1204,6 +1206,14 @@ __global__ __launch_bounds__(256) void k_divergence(const S* __restrict__ u, con
     }
 }
 
+// 64-lane butterfly maximum (the reductions further down, and k_subtract_gradient_max)
+__device__ __forceinline__ float wave_max(float m)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    return m;
+}
+
 // ---------------------------------------------------------------------------
 // a7  pressure-gradient subtraction (FluidSequential.c:161-173):
 // u -= (0.5f*(pR-pL))/h ; v -= (0.5f*(pD-pU))/h ; set_bnd(1,u), set_bnd(2,v).
@@ -1225,6 +1235,49 @@ __global__ __launch_bounds__(256) void k_subtract_gradient(S* __restrict__ u, S*
     st1(v + c, nv);
     emit_ghosts(u, P, n, 1, j, i, nu);
     emit_ghosts(v, P, n, 2, j, i, nv);
+}
+
+// The same with max(|u|, |v|) of what it stores (k_absmax2's result over the same rows, interior cells) reduced on the
+// way: on row slabs the advection that follows needs that bound on the host before it can start, and a reduction pass of
+// its own costs as much as this whole kernel.  Every block leaves its maximum in partials[]; k_max_partials (one block)
+// folds them into the result word.  No atomics (thousands of them on one word serialise at ~12 ns each) and no memset.
+template <typename S>
+__global__ __launch_bounds__(256) void k_subtract_gradient_max(S* __restrict__ u, S* __restrict__ v, const S* __restrict__ p,
+                                                               int pitch, int n, int row_lo, int row_hi, float h,
+                                                               float* __restrict__ partials)
+{
+    const int j = 1 + blockIdx.x * 256 + threadIdx.x;
+    const size_t P = (size_t)pitch;
+    float m = 0.0f;
+    if (j <= n)
+        for (int i = row_lo + blockIdx.y; i < row_hi; i += gridDim.y) {
+            const size_t c = (size_t)i * P + XOFF + j;
+            const float gx = 0.5f * (ld1(p + c + 1) - ld1(p + c - 1));
+            const float gy = 0.5f * (ld1(p + c + P) - ld1(p + c - P));
+            const float nu = ld1(u + c) - gx / h;
+            const float nv = ld1(v + c) - gy / h;
+            st1(u + c, nu);
+            st1(v + c, nv);
+            emit_ghosts(u, P, n, 1, j, i, nu);
+            emit_ghosts(v, P, n, 2, j, i, nv);
+            m = fmaxf(m, fmaxf(fabsf(as_stored<S>(nu)), fabsf(as_stored<S>(nv))));
+        }
+    __shared__ float part[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+}
+
+__global__ __launch_bounds__(256) void k_max_partials(const float* __restrict__ partials, int count, unsigned int* __restrict__ result)
+{
+    float m = 0.0f;
+    for (int k = threadIdx.x; k < count; k += 256) m = fmaxf(m, partials[k]);
+    __shared__ float part[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) *result = __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
 }
 
 // The last two operators of a step in one pass (FluidSequential.c:240 + :185): the gradient subtraction
@@ -1286,13 +1339,6 @@ __global__ __launch_bounds__(256) void k_gradient_advect(S* __restrict__ u, S* _
 //               on the uint view is exact and order independent).
 //   k_residual: max |beta*x - alpha*(L+R+U+D) - x0| over the same cells.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float wave_max(float m)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    return m;
-}
-
 // wave maxima -> block maximum (LDS) -> ONE atomic per block: contended atomics on a single word
 // serialise at ~12 ns each, so one per wave from thousands of waves costs more than the reduction.
 __device__ __forceinline__ void block_max_to(unsigned int* __restrict__ result, float m)
@@ -1526,9 +1572,17 @@ void launch_divergence(hipStream_t s, int st, const void* u, const void* v, void
 }
 
 void launch_subtract_gradient(hipStream_t s, int st, void* u, void* v, const void* p, int pitch, int n, int row_lo,
-                              int row_hi, float h)
+                              int row_hi, float h, float* partials, unsigned int* max_out)
 {
     if (row_hi <= row_lo) return;
+    if (max_out) {
+        const unsigned per_col = cdiv(n, 256), rows = (unsigned)(row_hi - row_lo);
+        const unsigned gy = std::max(1u, std::min(rows, (unsigned)kMaxPartials / per_col));     // a few rows per block
+        FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_subtract_gradient_max<S>, dim3(per_col, gy), dim3(256), 0, s, (S*)u, (S*)v,
+                                                (const S*)p, pitch, n, row_lo, row_hi, h, partials));
+        hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(256), 0, s, partials, (int)(per_col * gy), max_out);
+        return;
+    }
     FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_subtract_gradient<S>, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s,
                                             (S*)u, (S*)v, (const S*)p, pitch, n, row_lo, row_hi, h));
 }

@@ -774,12 +774,16 @@ int op_diffuse(fluid_ctx* c, int b, int x, int x0, float alpha, float beta, int 
 // The bound is a host decision, i.e. a pipeline drain: vmax_begin() only
 // enqueues (reduction kernel, device-side all-reduce, copy to pinned memory),
 // so the caller can put independent work behind it before advect_halo() waits.
-int vmax_begin(fluid_ctx* c, int u, int v)
+// `have_max`: the gradient subtraction that has just produced (u, v) left their maximum in the device word already
+// (op_subtract_gradient with_max)
+int vmax_begin(fluid_ctx* c, int u, int v, bool have_max = false)
 {
     if (c->nranks == 1) return FLUID_OK;
-    TRY(materialize(c, {u, v}));
-    HIP_TRY(hipMemsetAsync(c->d_scalar, 0, sizeof(unsigned), c->stream));
-    fluid::launch_absmax2(c->stream, c->st, c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, c->d_scalar);
+    if (!have_max) {
+        TRY(materialize(c, {u, v}));
+        HIP_TRY(hipMemsetAsync(c->d_scalar, 0, sizeof(unsigned), c->stream));
+        fluid::launch_absmax2(c->stream, c->st, c->f[u], c->f[v], c->pitch, c->n, c->own0, c->own1, c->d_scalar);
+    }
     TRY(exchange(c, FLUID_XCHG_MAX_BEGIN, {}, 0));       // in-place MAX over ranks on the device scalar
     HIP_TRY(hipMemcpyAsync(c->h_scalar, c->d_scalar, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->scalar_ready, c->stream));
@@ -864,14 +868,18 @@ int op_divergence(fluid_ctx* c, int u, int v, int p, int div, int want = 0)
     return FLUID_OK;
 }
 
-int op_subtract_gradient(fluid_ctx* c, int u, int v, int p)
+// `with_max` (slabs): max(|u|, |v|) of the result, over the slab's own rows, is left in the device word for the
+// vmax_begin(.., have_max) that follows -- the bound of the advection along (u, v), without a pass of its own
+int op_subtract_gradient(fluid_ctx* c, int u, int v, int p, bool with_max = false)
 {
     if (p == u || p == v || u == v) return fail(FLUID_E_INVALID, "subtract_gradient: fields must be distinct");
     const float h = 1.0f / (float)c->n;
     TRY(materialize(c, {u, v, p}));
     TRY(need(c, {p}, 1));
+    with_max = with_max && c->nranks > 1 && c->d_partials;
     TIMED(c, FLUID_TIME_PROJECTION,
-          fluid::launch_subtract_gradient(c->stream, c->st, c->f[u], c->f[v], c->f[p], c->pitch, c->n, c->own0, c->own1, h));
+          fluid::launch_subtract_gradient(c->stream, c->st, c->f[u], c->f[v], c->f[p], c->pitch, c->n, c->own0, c->own1, h,
+                                          c->d_partials, with_max ? c->d_scalar : nullptr));
     wrote(c, u, 0);
     wrote(c, v, 0);
     return FLUID_OK;
@@ -931,7 +939,8 @@ bool divergence_fuses(fluid_ctx* c, int iters, int reach)
     return division_mode(c, 4.0f, 1.0f).mode == 4;
 }
 
-int project(fluid_ctx* c, int u, int v, int p, int div, int iters, const AdvectAfter* then_advect = nullptr)
+// `with_max` (slabs): see op_subtract_gradient
+int project(fluid_ctx* c, int u, int v, int p, int div, int iters, const AdvectAfter* then_advect = nullptr, bool with_max = false)
 {
     // rows past the slab on which the divergence is wanted (so that the solve needs no exchange of its own), as op_divergence
     const int reach = c->nranks > 1 ? std::max(0, std::min(std::min(iters, c->halo - 1), exchange_cap(c) - 1)) : 0;
@@ -953,7 +962,7 @@ int project(fluid_ctx* c, int u, int v, int p, int div, int iters, const AdvectA
         TRY(rc);
         wrote(c, div, 0);
         if (then_advect) return op_gradient_advect(c, u, v, p, then_advect->b, then_advect->d, then_advect->d0, then_advect->dt);
-        return op_subtract_gradient(c, u, v, p);
+        return op_subtract_gradient(c, u, v, p, with_max);
     }
     TRY(op_divergence(c, u, v, p, div, std::min(iters, c->halo - 1)));
     c->in_pressure_solve = true;            // timing only: reported separately (fluid_timing::pressure_ms)
@@ -961,7 +970,7 @@ int project(fluid_ctx* c, int u, int v, int p, int div, int iters, const AdvectA
     c->in_pressure_solve = false;
     TRY(rc_solve);
     if (then_advect) return op_gradient_advect(c, u, v, p, then_advect->b, then_advect->d, then_advect->d0, then_advect->dt);
-    return op_subtract_gradient(c, u, v, p);
+    return op_subtract_gradient(c, u, v, p, with_max);
 }
 
 // FluidSequential.c:189-241 with the SWAPs resolved into field roles:
@@ -978,9 +987,10 @@ int vel_step(fluid_ctx* c, float dt, float visc, int iters)
     TRY(need(c, {U, V, U0, V0}, h));
     const Solve uv[2] = {{1, U0, U, alpha, beta}, {2, V0, V, alpha, beta}};
     TRY(op_diffuse_batch(c, uv, 2, iters));
-    TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
+    TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters, nullptr, /*with_max=*/true));
     const float dt0 = dt * (float)c->n;
-    TRY(advect_prepare(c, {U0, V0}, U0, V0, dt0));
+    TRY(vmax_begin(c, U0, V0, /*have_max=*/true));
+    TRY(advect_halo(c, {U0, V0}, dt0));
     TRY(op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt));
     return project(c, U, V, /*p=*/U0, /*div=*/V0, iters);
 }
@@ -1065,11 +1075,12 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
         TRY(rc_dens);
         HIP_TRY(e_join);
         TRY(op_diffuse_batch(c, all, 2, iters));
-        TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
-        TRY(advect_prepare(c, {U0, V0}, U0, V0, dt0));
+        TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters, nullptr, /*with_max=*/true));
+        TRY(vmax_begin(c, U0, V0, /*have_max=*/true));
+        TRY(advect_halo(c, {U0, V0}, dt0));
         TRY(op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt));
-        TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters));
-        TRY(vmax_begin(c, U, V));
+        TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters, nullptr, /*with_max=*/true));
+        TRY(vmax_begin(c, U, V, /*have_max=*/true));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
         TRY(advect_halo(c, {D0}, dt0));
         return op_advect(c, 0, D, D0, U, V, dt);
@@ -1077,13 +1088,13 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
     const int rest = fill1 + fill2, head = iters - rest;
     if (head > 0) TRY(op_diffuse_batch(c, all, 3, head));
     if (rest > 0) TRY(op_diffuse_batch(c, all, 2, rest));
-    TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters));
-    TRY(vmax_begin(c, U0, V0));
+    TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters, nullptr, /*with_max=*/true));
+    TRY(vmax_begin(c, U0, V0, /*have_max=*/true));
     if (fill1 > 0) TRY(op_diffuse_batch(c, all + 2, 1, fill1));
     TRY(advect_halo(c, {U0, V0}, dt0));
     TRY(op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt));
-    TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters));
-    TRY(vmax_begin(c, U, V));
+    TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters, nullptr, /*with_max=*/true));
+    TRY(vmax_begin(c, U, V, /*have_max=*/true));
     if (fill2 > 0) TRY(op_diffuse_batch(c, all + 2, 1, fill2));
     TRY(advect_halo(c, {D0}, dt0));
     return op_advect(c, 0, D, D0, U, V, dt);
@@ -1265,6 +1276,7 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
         if (!hip_ok(hipMalloc((void**)&c->tiles, words * sizeof(unsigned)), "hipMalloc(tiles)")) return bail(rc);
         if (!hip_ok(hipMemsetAsync(c->tiles, 0, words * sizeof(unsigned), c->stream), "hipMemsetAsync(tiles)")) return bail(rc);
     }
+    if (P > 1 && !hip_ok(hipMalloc((void**)&c->d_partials, fluid::kMaxPartials * sizeof(float)), "hipMalloc(partials)")) return bail(rc);
     if (!hip_ok(hipHostMalloc((void**)&c->h_scalar, 256, hipHostMallocDefault), "hipHostMalloc")) return bail(rc);
     if (!hip_ok(hipEventCreateWithFlags(&c->scalar_ready, hipEventDisableTiming), "hipEventCreate")) return bail(rc);
     if (!hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return bail(rc);
@@ -1306,6 +1318,7 @@ int fluid_destroy(fluid_ctx* c)
     c->rccl = nullptr;
     if (c->h_scalar) (void)hipHostFree(c->h_scalar);
     if (c->tiles) (void)hipFree(c->tiles);
+    if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->scalar_ready) (void)hipEventDestroy(c->scalar_ready);
     if (c->own_arena && c->arena) (void)hipFree(c->arena);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);

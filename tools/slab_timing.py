@@ -38,6 +38,8 @@ with F.FluidSolver(n, rank=P // 2 - 1 if P > 1 else 0, nranks=P) as s:
     x[max(lo - 64, 0):hi + 64] = rng.random((min(hi + 64, n + 2) - max(lo - 64, 0), n + 2), dtype=np.float32)
     for name in ("u", "v", "dens"):
         s.upload_rows(name, x, max(lo - 64, 0), min(hi + 64, n + 2))
+    if os.environ.get("T16MIN"):
+        s.set_param(capi.PARAM_TB_T16_MIN_CELLS, int(os.environ["T16MIN"]))
     if os.environ.get("TB_T"):
         s.set_param(capi.PARAM_TB_MAX_SWEEPS, int(os.environ["TB_T"]))
     for rows in rows_list:
