@@ -15,6 +15,12 @@ pytestmark = pytest.mark.gpu
 DT, VISC, DIFF = 0.016, 0.0025, 0.1
 
 
+@pytest.fixture(scope="module")
+def F():
+    import fluidsimulationcuda_amd as F
+    return F
+
+
 class FakeFabric:
     """Shared state of the P fake ranks: a barrier and everyone's field tensors."""
 
@@ -24,6 +30,7 @@ class FakeFabric:
         self.solvers = [None] * nranks
         self.scalars = [0.0] * nranks
         self.log = [[] for _ in range(nranks)]
+        self.maxima = [[] for _ in range(nranks)]      # the local bound each rank brought to every MAX exchange
 
     def make_callback(self, rank):
         import torch
@@ -37,6 +44,7 @@ class FakeFabric:
                 return None
             if kind in (capi.XCHG_MAX, capi.XCHG_MAX_END):
                 self.scalars[rank] = scalar
+                self.maxima[rank].append(scalar)
                 self.barrier.wait()
                 out = max(self.scalars)
                 self.barrier.wait()
@@ -307,3 +315,46 @@ def test_slabs_with_16_sweep_launches(n, nranks, halo):
         assert fab.log[r] == fab.log[0]
     for k in ("u", "v", "dens"):
         assert_bit_equal(got[k], want[k], "%s, %d slabs, T=16 forced" % (k, nranks))
+
+
+@pytest.mark.parametrize("storage", [0, 1])
+@pytest.mark.parametrize("n,nranks", [(126, 2), (257, 3), (1022, 4)])
+def test_advect_bounds_from_the_gradient_subtraction_are_the_slabs_own_maxima(F, n, nranks, storage):
+    """Inside fluid_step / fluid_vel_step the bound of each advection -- max(|u|, |v|) over the slab's own rows -- is
+    reduced by the gradient subtraction that produces the velocity (k_subtract_gradient_max + k_max_partials), not by
+    k_absmax2.  Every value a rank brings to a MAX exchange is compared with numpy's maximum over that rank's rows of
+    the same velocity, taken from a one-context replay of the step through the operators (FluidSequential.c:189-241)."""
+    from fluidsimulationcuda_amd import capi
+    from fluidsimulationcuda_amd.slab import slab_rows
+    fields = synthetic(n, seed=31 + n)
+    want = []                                           # (u, v) as each advection sees them
+    av, bv = F.coefficients(n, DT, VISC)
+    ad, bd = F.coefficients(n, DT, DIFF)
+    with F.FluidSolver(n, storage=storage, params={capi.PARAM_TB_MIN_CELLS: 0}) as s:
+        s.upload(**fields)
+        for x, src in (("u", "u_prev"), ("v", "v_prev"), ("dens", "dens_prev")):
+            s.add_source(x, src)
+        s.diffuse(1, "u_prev", "u", av, bv)
+        s.diffuse(2, "v_prev", "v", av, bv)
+        s.diffuse(0, "dens_prev", "dens", ad, bd)
+        s.computeDivergenceAndPressure("u_prev", "v_prev", "u", "v")
+        s.diffuse(0, "u", "v", 1.0, 4.0)
+        s.lastProject("u_prev", "v_prev", "u")
+        want.append((s.download("u_prev"), s.download("v_prev")))
+        s.advect(1, "u", "u_prev", "u_prev", "v_prev")
+        s.advect(2, "v", "v_prev", "u_prev", "v_prev")
+        s.computeDivergenceAndPressure("u", "v", "u_prev", "v_prev")
+        s.diffuse(0, "u_prev", "v_prev", 1.0, 4.0)
+        s.lastProject("u", "v", "u_prev")
+        want.append((s.download("u"), s.download("v")))
+        s.advect(0, "dens", "dens_prev", "u", "v")
+        one = {k: s.download(k) for k in ("u", "v", "dens")}
+    got, fab = run_ranks(n, nranks, 0, fields, lambda s: s.step(1, use_sources=True), jacobi=3, storage=storage)
+    for k in ("u", "v", "dens"):
+        assert_bit_equal(got[k], one[k], "%s: step on %d slabs vs the operators in one context" % (k, nranks))
+    for r in range(nranks):
+        lo, hi = slab_rows(n, r, nranks)
+        assert len(fab.maxima[r]) == 2
+        for k, (u, v) in enumerate(want):
+            m = max(np.abs(u[lo:hi, 1:n + 1]).max(), np.abs(v[lo:hi, 1:n + 1]).max())
+            assert np.float32(fab.maxima[r][k]).view(np.uint32) == np.float32(m).view(np.uint32), (r, k, fab.maxima[r][k], m)
