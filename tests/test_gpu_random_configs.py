@@ -3,12 +3,17 @@ together -- grid size, sweep count, launch depth, lanes, strip height, division 
 so that interactions between the round-2 paths (planned depths, 12-sweep launches, divergence inside the pressure solve,
 second stream on slabs) are exercised.  One GPU: two steps against the oracle, all six fields.  Slabs (in-process
 fabric): two steps against one context, plus the requirement that every rank issues the same exchange sequence."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import assert_bit_equal, rnd
 
 pytestmark = pytest.mark.gpu
+# more seeds for a one-off soak: FLUID_FUZZ_SINGLE=2000 FLUID_FUZZ_SLABS=500 python -m pytest tests/test_gpu_random_configs.py
+N_SINGLE = int(os.environ.get("FLUID_FUZZ_SINGLE", "160"))
+N_SLABS = int(os.environ.get("FLUID_FUZZ_SLABS", "64"))
 
 
 def random_params(rng, capi):
@@ -24,7 +29,7 @@ def random_params(rng, capi):
     return p
 
 
-@pytest.mark.parametrize("seed", range(160))
+@pytest.mark.parametrize("seed", range(N_SINGLE))
 def test_random_single_gpu_configuration_matches_oracle(oracle, seed):
     import fluidsimulationcuda_amd as F
     from fluidsimulationcuda_amd import capi
@@ -49,7 +54,7 @@ def test_random_single_gpu_configuration_matches_oracle(oracle, seed):
             assert_bit_equal(s.download(name), want, name + " -- " + what)
 
 
-@pytest.mark.parametrize("seed", range(64))
+@pytest.mark.parametrize("seed", range(N_SLABS))
 def test_random_slab_configuration_matches_one_context(seed):
     from test_gpu_slab import run_ranks, single
     from fluidsimulationcuda_amd import capi
