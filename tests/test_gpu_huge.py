@@ -5,6 +5,8 @@ grid of 10^9 cells in test time, and none is needed: every operator here is loca
 (FluidSequential.c, cited per check) is evaluated in numpy float32 at a few thousand SAMPLED cells -- the four corners'
 neighbourhoods, the walls, the last rows (the highest addresses), random interior cells -- and compared bit for bit.
 Fields are a 1024 x 1024 random block tiled over the grid (cheap to make, still different at every sampled stencil)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -48,7 +50,11 @@ def ghost_checks(x, b, n, what):
         bits_equal(x[gi, gj], f32(0.5) * (x[ai, aj] + x[bi, bj]), what + ": corner")
 
 
-@pytest.mark.parametrize("n", [24000, 32800])
+# FLUID_HUGE_N=65533 adds the largest grid the library takes (17 GiB per field; ~150 GiB of host memory for this test)
+SIZES = [24000, 32800] + ([int(os.environ["FLUID_HUGE_N"])] if os.environ.get("FLUID_HUGE_N") else [])
+
+
+@pytest.mark.parametrize("n", SIZES)
 def test_operators_at_sampled_cells_of_a_huge_grid(n):
     import fluidsimulationcuda_amd as F
     u, v, d = tiled(n, 1), tiled(n, 2), tiled(n, 3, 0.0, 1.0)
