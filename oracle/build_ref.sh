@@ -23,7 +23,7 @@ fi
 mkdir -p "$out"
 pairs=("$@")
 if [ ${#pairs[@]} -eq 0 ]; then
-    pairs=(14:40 30:40 61:40 126:40 126:20 254:40 1022:40 4094:40 8190:40)
+    pairs=(14:40 30:40 61:40 126:40 126:20 254:40 1022:40 4094:40 8190:40 16382:40)
 fi
 for pr in "${pairs[@]}"; do
     n="${pr%%:*}"; k="${pr##*:}"

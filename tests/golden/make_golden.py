@@ -164,7 +164,7 @@ def checksums():
     pure-python hash is affordable."""
     import zlib
     rows = []
-    for n in (254, 1022, 4094, 8190):
+    for n in (254, 1022, 4094, 8190, 16382):
         r = Reference(n, 40)
         dens, dens0, u, u0, v, v0 = r.initialize(seed=1)
         r.step_src(u, v, dens, u0, v0, dens0)

@@ -1,5 +1,6 @@
 """GPU: BASELINE configs 3 and 4 at their own sizes -- 8192^2 (fp32, one context and row slabs) and
-16384^2 (fp16 storage) -- against the oracle itself, not against another HIP path.  These sizes select
+16384^2 (fp16 storage; fp32 against the reference's own checksums and a windowed oracle) -- against the oracle itself, not
+against another HIP path.  These sizes select
 kernels no smaller grid reaches by default: 16-sweep fused launches of the general (diffusion) form need a
 field of more than 96 MiB.  Every test asserts the launch schedule it means to exercise.
 
@@ -101,7 +102,7 @@ def test_two_steps_at_8192_match_oracle_and_two_slabs(F, oracle):
         assert_bit_equal(one[k], w[k], "%s after two steps at 8192^2" % k)
 
 
-@pytest.mark.parametrize("n", [1022, 4094, 8190])
+@pytest.mark.parametrize("n", [1022, 4094, 8190, 16382])
 def test_reference_crc_at_full_size(F, n):
     """Step 1 from the reference's own initializeParameters (glibc rand, seed 1): CRC-32 of the bytes of u, v
     and dens as the compiled reference left them (tests/golden/checksums.json, make_golden.py)."""
@@ -163,3 +164,43 @@ def test_fp16_two_slabs_at_16384_match_one_context(F):
     assert fab.log[1] == fab.log[0]
     for k in ("u", "v", "dens"):
         assert_bit_equal(got[k], one[k], "%s: 2 slabs vs one context at 16384^2, fp16 storage" % k)
+
+
+@pytest.mark.parametrize("form", ["pressure", "viscosity"])
+def test_40_sweep_solve_at_16384_fp32_matches_windowed_oracle(F, oracle, form):
+    """16384^2 in fp32 (1 GiB per field; bench.py --grid 16384): a full-grid oracle solve takes minutes, but a cell after
+    k sweeps depends only on the (2k+1)^2 cells around it, so the oracle runs on WINDOWS: 83 x 83 cells cut out around a
+    sampled cell (41 > 40 sweeps from the cut, so what the oracle's set_bnd does to the cut edge never reaches the centre),
+    or cut flush with the domain's walls and corners, where the window's own ghost ring IS the domain's and set_bnd
+    (FluidSequential.c:62-75) is replayed for real.  Bit equality at every cell the cut cannot have touched."""
+    n, iters = 16382, 40
+    r = iters + 1
+    rng = np.random.default_rng(160 + len(form))
+    b, (alpha, beta) = {"pressure": (0, (1.0, 4.0)), "viscosity": (1, F.coefficients(n, DT, VISC))}[form]
+    x, x0 = rnd(rng, n), rnd(rng, n)
+    with F.FluidSolver(n) as s:
+        s.upload(u=x, v=x0)
+        s.timing_enable(True)
+        s.timing_read(reset=True)
+        s.diffuse(b, "u", "v", alpha, beta, iters)
+        t = s.timing_read(reset=True)
+        got = s.download("u")
+    assert t["jacobi_launches"] == 3 and t["sweeps"] == iters, t          # 16 + 12 + 12
+    w = 2 * r + 1
+    # window origins (row, col of the window's ghost ring): flush with each wall / corner, and random interior ones
+    lo, hi = 0, n + 2 - w
+    origins = [(lo, lo), (lo, hi), (hi, lo), (hi, hi), (lo, 5000), (hi, 7001), (4000, lo), (9000, hi)]
+    origins += [(int(a), int(c)) for a, c in zip(rng.integers(1, hi, 24), rng.integers(1, hi, 24))]
+    origins += [(8191 - r, 8191 - r), (16382 - w, 3), (3, 16382 - w), (128 * 40 - r, 96 * 50 - r)]   # strip / window seams
+    for (i0, j0) in origins:
+        xw = np.ascontiguousarray(x[i0:i0 + w, j0:j0 + w])
+        x0w = np.ascontiguousarray(x0[i0:i0 + w, j0:j0 + w])
+        oracle.diffuse(b, xw, x0w, alpha, beta, iters)
+        # cells the cut can have reached: within `iters` of a cut edge (a side that lies on the domain's wall is no cut)
+        a0 = 0 if i0 == 0 else iters + 1
+        a1 = w if i0 + w == n + 2 else w - iters - 1
+        c0 = 0 if j0 == 0 else iters + 1
+        c1 = w if j0 + w == n + 2 else w - iters - 1
+        assert a1 > a0 and c1 > c0
+        assert_bit_equal(got[i0 + a0:i0 + a1, j0 + c0:j0 + c1], xw[a0:a1, c0:c1],
+                         "%s solve at 16384^2, window at (%d, %d)" % (form, i0, j0))
