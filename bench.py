@@ -368,7 +368,7 @@ def main():
     achieved = bpc * cells / t_sweep / 1e9
     launches = max(t["jacobi_launches"], 1)
     per_launch = sweeps / launches                       # field-sweeps per launch (a batched launch sweeps 3 fields)
-    kernel_name = ("k_jacobi_tb (8 or 16 sweeps + set_bnd per launch, up to 3 fields per launch; %.1f launches/step)"
+    kernel_name = ("k_jacobi_tb (8, 12 or 16 sweeps + set_bnd per launch, up to 3 fields per launch; %.1f launches/step)"
                    % (launches / a.steps)) if a.variant == 3 else "k_jacobi_%s (one sweep + fused set_bnd)" % KERNELS[a.variant]
     arith = "fp32" if a.dtype == "f32" else "fp16 storage, fp32 arithmetic"
     line = {
