@@ -229,6 +229,18 @@ def cpu_baseline(n, fields, iters):
 
 def main():
     a = parse()
+    # stdout carries ONE line, the JSON: libraries that write to file descriptor 1 themselves (RCCL prints its host name
+    # and library path there when a communicator comes up) go to stderr until that line is due
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        print(json.dumps(obj), flush=True)
+        os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -336,7 +348,7 @@ def main():
     if a.only_ordinary:
         e, j, p, t, copy_ms, solve = run_ordinary(n, a.steps, a.warmup)
         r = rates(e, j, p, t, a.steps, cells, solve)
-        print(json.dumps({"value_ordinary_data": r, "copy_ms_per_step": copy_ms}), flush=True)
+        emit({"value_ordinary_data": r, "copy_ms_per_step": copy_ms})
         return
 
     if a.check and world > 1:
@@ -484,7 +496,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(n, fields, a.iters)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
