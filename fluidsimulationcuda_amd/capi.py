@@ -21,6 +21,7 @@ PARAM_TB_T16_MIN_CELLS = 7
 PARAM_TB_AUTOTUNE = 8
 PARAM_FUSE_DIVERGENCE = 9
 PARAM_SLAB_OVERLAP = 10
+PARAM_EARLY_ADVECT = 11
 XCHG_HALO, XCHG_GATHER, XCHG_MAX, XCHG_MAX_BEGIN, XCHG_MAX_END = 0, 1, 2, 3, 4
 RCCL_ID_BYTES = 128
 FIELD_NAMES = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev", "tmp0", "tmp1", "tmp2")

@@ -41,6 +41,8 @@ struct fluid_ctx {
     hipStream_t stream2 = nullptr;        // slabs: the density diffusion runs beside the velocity path (full_step)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool slab_overlap = true;
+    bool early_advect = true;                      // FLUID_PARAM_EARLY_ADVECT
+    float vmax_prev[2] = {-1.0f, -1.0f};           // the last global bounds of the velocity / density advection (-1: none yet)
     void* f[FLUID_NFIELDS] = {};
     size_t field_bytes = 0;
     unsigned int* d_scalar = nullptr;     // device word for the reductions

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -806,6 +807,42 @@ int advect_halo(fluid_ctx* c, std::initializer_list<int> sources, float dt0)
     return need(c, sources, (int)reach);
 }
 
+// vmax_begin() has been enqueued; `run` enqueues the advection of `sources` (FluidSequential.c:107-141) along that velocity.
+// The classic order -- wait for the bound, bring in that many rows, advect -- leaves the GPU idle while the host reads the
+// bound and enqueues the rest.  Velocities change little from step to step, so with a bound from the previous step at
+// hand (slot 0: the velocity's own advection, 1: the density's) the exchange and the advection are enqueued FIRST, on
+// that bound plus a quarter, and the host then checks the new bound against it: the same on every rank (both are
+// all-reduced values), so all ranks agree on whether to do it over.  Doing it over is safe: an advection writes fields
+// it does not read, and nothing that overwrites its inputs is enqueued before this function returns.
+int advect_bounded(fluid_ctx* c, int slot, std::initializer_list<int> sources, float dt0, const std::function<int()>& run)
+{
+    if (c->nranks == 1) return run();
+    int guess = 0;
+    const float prev = c->vmax_prev[slot];
+    if (c->early_advect && prev >= 0.0f) {
+        const double g = std::ceil((double)std::fabs(dt0) * (double)prev * 1.25) + 2.0;
+        if (g <= (double)exchange_cap(c)) {
+            guess = (int)g;
+            TRY(need(c, sources, guess));
+            TRY(run());
+        }
+    }
+    HIP_TRY(hipEventSynchronize(c->scalar_ready));
+    float vmax = 0.f;
+    std::memcpy(&vmax, c->h_scalar, sizeof vmax);
+    TRY(exchange(c, FLUID_XCHG_MAX_END, {}, 0, &vmax));  // transports that reduce on the host finish here
+    const double reach = std::ceil((double)std::fabs(dt0) * (double)vmax) + 2.0;
+    c->vmax_prev[slot] = std::isfinite(vmax) ? vmax : -1.0f;
+    if (guess > 0 && reach <= (double)guess) return FLUID_OK;
+    if (!(reach <= (double)exchange_cap(c))) {     // also catches NaN/inf
+        TRY(exchange(c, FLUID_XCHG_GATHER, sources, 0));
+        for (int f : sources) c->reach[f] = kEverywhere;
+    } else {
+        TRY(need(c, sources, (int)reach));
+    }
+    return run();
+}
+
 int advect_prepare(fluid_ctx* c, std::initializer_list<int> sources, int u, int v, float dt0)
 {
     TRY(vmax_begin(c, u, v));
@@ -990,8 +1027,7 @@ int vel_step(fluid_ctx* c, float dt, float visc, int iters)
     TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters, nullptr, /*with_max=*/true));
     const float dt0 = dt * (float)c->n;
     TRY(vmax_begin(c, U0, V0, /*have_max=*/true));
-    TRY(advect_halo(c, {U0, V0}, dt0));
-    TRY(op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt));
+    TRY(advect_bounded(c, 0, {U0, V0}, dt0, [&] { return op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt); }));
     return project(c, U, V, /*p=*/U0, /*div=*/V0, iters);
 }
 
@@ -1003,8 +1039,8 @@ int dens_step(fluid_ctx* c, float dt, float diff, int iters)
     TRY(op_add_source(c, X, X0, dt));
     coefficients(c->n, dt, diff, &alpha, &beta);
     TRY(op_diffuse(c, 0, X0, X, alpha, beta, iters));
-    TRY(advect_prepare(c, {X0}, FLUID_U, FLUID_V, dt * (float)c->n));
-    return op_advect(c, 0, X, X0, FLUID_U, FLUID_V, dt);
+    TRY(vmax_begin(c, FLUID_U, FLUID_V));
+    return advect_bounded(c, 1, {X0}, dt * (float)c->n, [&] { return op_advect(c, 0, X, X0, FLUID_U, FLUID_V, dt); });
 }
 
 // One loop body of the reference's main (FluidSequential.c:305-306).  The density's
@@ -1077,13 +1113,11 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
         TRY(op_diffuse_batch(c, all, 2, iters));
         TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters, nullptr, /*with_max=*/true));
         TRY(vmax_begin(c, U0, V0, /*have_max=*/true));
-        TRY(advect_halo(c, {U0, V0}, dt0));
-        TRY(op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt));
+        TRY(advect_bounded(c, 0, {U0, V0}, dt0, [&] { return op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt); }));
         TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters, nullptr, /*with_max=*/true));
         TRY(vmax_begin(c, U, V, /*have_max=*/true));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        TRY(advect_halo(c, {D0}, dt0));
-        return op_advect(c, 0, D, D0, U, V, dt);
+        return advect_bounded(c, 1, {D0}, dt0, [&] { return op_advect(c, 0, D, D0, U, V, dt); });
     }
     const int rest = fill1 + fill2, head = iters - rest;
     if (head > 0) TRY(op_diffuse_batch(c, all, 3, head));
@@ -1091,13 +1125,11 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
     TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters, nullptr, /*with_max=*/true));
     TRY(vmax_begin(c, U0, V0, /*have_max=*/true));
     if (fill1 > 0) TRY(op_diffuse_batch(c, all + 2, 1, fill1));
-    TRY(advect_halo(c, {U0, V0}, dt0));
-    TRY(op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt));
+    TRY(advect_bounded(c, 0, {U0, V0}, dt0, [&] { return op_advect2(c, 1, U, U0, 2, V, V0, U0, V0, dt); }));
     TRY(project(c, U, V, /*p=*/U0, /*div=*/V0, iters, nullptr, /*with_max=*/true));
     TRY(vmax_begin(c, U, V, /*have_max=*/true));
     if (fill2 > 0) TRY(op_diffuse_batch(c, all + 2, 1, fill2));
-    TRY(advect_halo(c, {D0}, dt0));
-    return op_advect(c, 0, D, D0, U, V, dt);
+    return advect_bounded(c, 1, {D0}, dt0, [&] { return op_advect(c, 0, D, D0, U, V, dt); });
 }
 
 int zero_sources(fluid_ctx* c)
@@ -1448,6 +1480,9 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
         return FLUID_OK;
     case FLUID_PARAM_FUSE_DIVERGENCE:
         c->fuse_divergence = value != 0;
+        return FLUID_OK;
+    case FLUID_PARAM_EARLY_ADVECT:
+        c->early_advect = value != 0;
         return FLUID_OK;
     case FLUID_PARAM_TB_T16_MIN_CELLS:
         if (value < -1) return fail(FLUID_E_INVALID, "TB_T16_MIN_CELLS must be >= 0, or -1 for the default rule");

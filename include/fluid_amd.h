@@ -75,6 +75,10 @@ enum {
     ,FLUID_PARAM_SLAB_OVERLAP = 10 /* 1 (default): on row slabs fluid_step runs the density diffusion on a second stream
                                       beside the velocity path (a slab's launches leave most of the chip idle), when the
                                       ghost zones cover a whole solve; 0: one stream.  Speed only.                */
+    ,FLUID_PARAM_EARLY_ADVECT = 11 /* 1 (default): on row slabs fluid_step starts each advection on the PREVIOUS step's velocity
+                                      bound (+25 %) while the new bound is still on its way to the host, and repeats it in
+                                      the rare case the bound grew past that (its inputs are still intact then), so the
+                                      GPU does not idle while the host reads the bound; 0: wait first.  Speed only. */
     ,FLUID_PARAM_FUSE_DIVERGENCE = 9 /* 1 (default): inside fluid_step / fluid_vel_step on one GPU the divergence of a
                                       projection is computed by the first launch of the pressure solve that consumes it
                                       (no separate pass over u, v); 0: its own kernel first.  Speed only.        */

@@ -358,3 +358,48 @@ def test_advect_bounds_from_the_gradient_subtraction_are_the_slabs_own_maxima(F,
         for k, (u, v) in enumerate(want):
             m = max(np.abs(u[lo:hi, 1:n + 1]).max(), np.abs(v[lo:hi, 1:n + 1]).max())
             assert np.float32(fab.maxima[r][k]).view(np.uint32) == np.float32(m).view(np.uint32), (r, k, fab.maxima[r][k], m)
+
+
+@pytest.mark.parametrize("grow,expect", [(0.5, "kept"), (40.0, "repeated"), (4000.0, "gathered")])
+@pytest.mark.parametrize("entry", ["step", "vel_dens"])
+def test_advection_started_on_the_previous_bound(F, grow, expect, entry):
+    """Row slabs start each advection of a step on the bound of the step before (+25 %) while the new bound is still
+    on its way to the host (FLUID_PARAM_EARLY_ADVECT, advect_bounded in fluid_solver.hip).  Velocity sources that
+    shrink keep the early advection; sources that make the velocity jump force the exchange and the advection to be
+    repeated with the real bound -- or with whole gathered fields when that bound outgrows a slab.  Every case bit-identical
+    to one context, with and without the early start, and the exchange sequences show which way each advection went."""
+    from fluidsimulationcuda_amd import capi
+    n, nranks = 254, 3
+    first = synthetic(n, seed=77)
+    rng = np.random.default_rng(78)
+    second = {k: (first[k] * np.float32(grow) + rnd(rng, n, -0.001, 0.001)).astype(np.float32) for k in ("u_prev", "v_prev", "dens_prev")}
+
+    def body(s):
+        def go():
+            if entry == "step":
+                s.step(1, use_sources=True)
+            else:
+                s.vel_step()
+                s.dens_step()
+        go()
+        if isinstance(s, F.FluidSolver) and s.nranks > 1:
+            s.load_global(**second)
+        else:
+            s.upload(**second)
+        go()
+
+    want = single(n, first, body)
+    logs = {}
+    for early in (1, 0):
+        got, fab = run_ranks(n, nranks, 0, first, body, jacobi=3, params={capi.PARAM_EARLY_ADVECT: early})
+        for k in ("u", "v", "dens", "u_prev", "v_prev", "dens_prev"):
+            assert_bit_equal(got[k], want[k], "%s, early advect %d, sources x %g" % (k, early, grow))
+        assert fab.log[0] == fab.log[1] == fab.log[2]
+        logs[early] = [e[0] for e in fab.log[0]]
+    H, G = capi.XCHG_HALO, capi.XCHG_GATHER
+    halos = {k: v.count(H) for k, v in logs.items()}
+    gathers = {k: v.count(G) for k, v in logs.items()}
+    # first step: no previous bound, both runs alike.  Second step, two advections: an early start that holds costs no
+    # exchange more than waiting would; one that does not hold has sent its halo rows for nothing, once per advection
+    assert halos[1] - halos[0] == {"kept": 0, "repeated": 2, "gathered": 2}[expect], (halos, gathers)
+    assert gathers[1] == gathers[0] == (2 if expect == "gathered" else 0), (halos, gathers)
