@@ -2,7 +2,9 @@
 """TEST INFRASTRUCTURE (run as a subprocess by tests/test_gpu_rccl_mock.py with FLUID_RCCL_LIB pointing at the thread-ranks
 stand-in built from mock_rccl.cpp): P contexts, one thread each, all on this one GPU, exchange rows through the LIBRARY'S
 OWN exchange (csrc/fluid_exchange_rccl.hip) -- attach, steps, gather -- and must reproduce a single context bit for bit.
-    run_ranks.py N NRANKS HALO STORAGE ITERS [big_velocity]"""
+    run_ranks.py N NRANKS HALO STORAGE ITERS [big | grow]
+big: velocities whose back-traces outgrow a slab (the gather fall-back); grow: a fourth step whose sources make the
+velocity jump, so that the advections started on the previous step's bound must be repeated"""
 import ctypes as C
 import os
 import sys
@@ -19,7 +21,8 @@ from test_gpu_slab import _init_fake, single, synthetic  # noqa: E402
 from fluidsimulationcuda_amd.slab import SlabSolver  # noqa: E402
 
 n, nranks, halo, storage, iters = (int(x) for x in sys.argv[1:6])
-big = len(sys.argv) > 6
+big = len(sys.argv) > 6 and sys.argv[6] == "big"
+grow = len(sys.argv) > 6 and sys.argv[6] == "grow"
 assert os.environ.get("FLUID_RCCL_LIB"), "meant to run against the stand-in"
 L = capi.lib()
 fields = synthetic(n, seed=n + nranks)
@@ -29,9 +32,18 @@ if big:                                                     # back-traces longer
     fields["v_prev"] = (rng.random(fields["v_prev"].shape, dtype=np.float32) * 5000).astype(np.float32)
 
 
+more = {k: (fields[k] * np.float32(60)).astype(np.float32) for k in ("u_prev", "v_prev", "dens_prev")}
+
+
 def body(s):
     s.step(1, use_sources=True, iters=iters)
     s.step(2, iters=iters)
+    if grow:
+        if s.nranks > 1:
+            s.load_global(**more)
+        else:
+            s.upload(**more)
+        s.step(1, use_sources=True, iters=iters)
 
 
 want = single(n, fields, body, storage=storage)

@@ -35,15 +35,18 @@ def mock_lib(tmp_path_factory):
     (1022, 8, 0, 0, 40, False),       # eight ranks
     (254, 2, 40, 1, 20, False),       # fp16 rows (half the bytes), 8 + 8 + 4 schedule
     (126, 4, 4, 0, 8, True),          # back-traces longer than a slab: FLUID_XCHG_GATHER through grouped broadcasts
+    (254, 3, 0, 0, 40, "grow"),       # a fourth step whose velocity jumps: the early advections are repeated (advect_bounded)
 ])
 def test_thread_ranks_through_the_native_exchange(mock_lib, n, nranks, halo, storage, iters, big):
     env = dict(os.environ, FLUID_RCCL_LIB=mock_lib)
     cmd = [sys.executable, os.path.join(ROOT, "tests", "mock_rccl", "run_ranks.py"), str(n), str(nranks), str(halo), str(storage),
-           str(iters)] + (["big"] if big else [])
+           str(iters)] + (["grow"] if big == "grow" else ["big"] if big else [])
+    steps = 4 if big == "grow" else 3
+    big = big is True
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     last = p.stdout.strip().splitlines()[-1]
     assert last.startswith("ok: %d ranks" % nranks), last
     counts = dict(kv.split("=") for kv in last.split("in the steps: ")[1].split())
-    assert int(counts["max"]) == 2 * 3 and int(counts["halo"]) >= 3                      # two advect bounds per step, three steps
+    assert int(counts["max"]) == 2 * steps and int(counts["halo"]) >= 3                  # two advect bounds per step
     assert (int(counts["gather"]) > 0) == big, "the gather fall-back runs exactly when back-traces outgrow a slab: " + last
