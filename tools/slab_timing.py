@@ -2,7 +2,8 @@
 """Tuning aid: what ONE rank of an N-GPU run computes, timed on one GPU.
 A context configured as rank r of P with a no-op exchange callback executes the
 same kernels on the same row ranges as in a real run (the numbers it produces
-are meaningless: halos are never filled).   python tools/slab_timing.py [grid] [P] [rows...]"""
+are meaningless: halos are never filled).   python tools/slab_timing.py [grid] [P] [rows...]
+environment: HALO (ghost-zone depth), STORAGE (1: fp16 fields), T16MIN (FLUID_PARAM_TB_T16_MIN_CELLS), TB_T (most sweeps per launch)"""
 import os
 import sys
 import time
@@ -29,7 +30,8 @@ def xchg(kind, ids, depth, scalar):
     return None
 
 
-with F.FluidSolver(n, rank=P // 2 - 1 if P > 1 else 0, nranks=P) as s:
+with F.FluidSolver(n, rank=P // 2 - 1 if P > 1 else 0, nranks=P, halo=int(os.environ.get("HALO", "0")),
+                   storage=int(os.environ.get("STORAGE", "0"))) as s:
     if P > 1:
         s.set_exchange(xchg)
     rng = np.random.default_rng(0)
