@@ -444,6 +444,11 @@ int tune_pick(fluid_ctx* c, unsigned long long key, int heuristic, int T, long l
             if (r < 2 * T || r >= rows_n + 2 * T) continue;     // (a height past the rows is one strip: the tallest candidate covers it)
             if (std::find(e.cand.begin(), e.cand.end(), r) == e.cand.end()) e.cand.push_back(r);
         }
+        // small grids are bound by the latency of one wave's march, rb + 2T steps: strips shorter than the pipeline is
+        // deep pay there (256^2, 8 sweeps per launch: 0.21 ms per step at 4 rows against 0.26 at 16)
+        if (rows_n <= 1100)
+            for (int r : {4, 8, 12, 24, 32})
+                if (r < rows_n && std::find(e.cand.begin(), e.cand.end(), r) == e.cand.end()) e.cand.push_back(r);
         if (e.cand.size() == 1) {                                // nothing to choose from (tiny grids)
             e.fixed = heuristic;
             return heuristic;
