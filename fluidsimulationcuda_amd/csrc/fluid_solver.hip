@@ -447,7 +447,7 @@ int tune_pick(fluid_ctx* c, unsigned long long key, int heuristic, int T, long l
         // small grids are bound by the latency of one wave's march, rb + 2T steps: strips shorter than the pipeline is
         // deep pay there (256^2, 8 sweeps per launch: 0.21 ms per step at 4 rows against 0.26 at 16)
         if (rows_n <= 1100)
-            for (int r : {4, 8, 12, 24, 32})
+            for (int r : {2, 4, 8, 12, 24, 32})
                 if (r < rows_n && std::find(e.cand.begin(), e.cand.end(), r) == e.cand.end()) e.cand.push_back(r);
         if (e.cand.size() == 1) {                                // nothing to choose from (tiny grids)
             e.fixed = heuristic;
@@ -724,6 +724,9 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                     const int cap = T >= 16 ? 192 : (T >= 8 ? 80 : 96) * (m > 1 ? 2 : 1);
                     rb = 2 * T;
                     while (rb < cap && blocks(rb) > room) rb += 2;
+                    // small grids: a launch lasts as long as one wave's march of rb + 2T rows, and the best height
+                    // measured is about rows / 64 (2 at 128^2, 4 at 256^2, 8 at 512^2, 16 and more from 1024^2)
+                    if (rows_n <= 1100) rb = std::max(2, std::min(rb, (int)(rows_n / 64) & ~1));
                 }
                 // ... and that closed form is only the first candidate of the run-time tuner (see RbTuner)
                 int trial = -1;
