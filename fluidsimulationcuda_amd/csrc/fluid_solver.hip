@@ -446,8 +446,8 @@ int tune_pick(fluid_ctx* c, unsigned long long key, int heuristic, int T, long l
         }
         // small grids are bound by the latency of one wave's march, rb + 2T steps: strips shorter than the pipeline is
         // deep pay there (256^2, 8 sweeps per launch: 0.21 ms per step at 4 rows against 0.26 at 16)
-        if (rows_n <= 1100)
-            for (int r : {2, 4, 8, 12, 24, 32})
+        if (rows_n <= 2200)
+            for (int r : {2, 4, 8, 12, 24, 32, 40})
                 if (r < rows_n && std::find(e.cand.begin(), e.cand.end(), r) == e.cand.end()) e.cand.push_back(r);
         if (e.cand.size() == 1) {                                // nothing to choose from (tiny grids)
             e.fixed = heuristic;
