@@ -1104,6 +1104,43 @@ __device__ __forceinline__ int advect_col0() { return 1 + (int)blockIdx.x * 1024
 // does this block hold a cell next to a wall (wave-uniform)?  Only those run the ghost-cell code at all.
 __device__ __forceinline__ bool advect_wall_block(int i, int n) { return i == 1 || i == n || blockIdx.x == 0 || blockIdx.x == gridDim.x - 1; }
 
+// A wave's own 256 cells of a row, in and out, as ONE 16-byte access per lane instead of four 4-byte ones: the memory
+// side wants lane l to hold cells 4l .. 4l+3, the gathers want it to hold cells l, 64+l, 128+l, 192+l (above), and a
+// wave-private 1 KiB tile of LDS turns one into the other.  What these kernels wait for is the number of vector-memory
+// instructions the texture addresser has to take apart, about 21 cycles each per CU whatever their width: the
+// velocity loads and the result stores were half of them.  LDS executes a wave's instructions in order, so no barrier.
+// `p` points at the wave's first cell (16-byte aligned: column 1 sits on a 256-byte line and waves start 256 cells apart);
+// `cells` of the 256 exist (the rest of the row's last vector is pad; lanes past it repeat the last vector).
+template <typename S>
+__device__ __forceinline__ void wave_cells_in(const S* __restrict__ p, int cells, float* __restrict__ tile, float (&out)[4])
+{
+    const int lane = threadIdx.x & 63;
+    const int vec = min(lane, (cells - 1) >> 2);
+    *reinterpret_cast<float4*>(tile + 4 * lane) = ld4(p + 4 * vec);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = tile[lane + 64 * k];
+    __builtin_amdgcn_wave_barrier();
+}
+template <typename S>
+__device__ __forceinline__ void wave_cells_out(S* __restrict__ p, int cells, float* __restrict__ tile, const float (&val)[4])
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[lane + 64 * k] = val[k];
+    __builtin_amdgcn_wave_barrier();
+    const float4 y = *reinterpret_cast<const float4*>(tile + 4 * lane);
+    __builtin_amdgcn_wave_barrier();
+    const int left = cells - 4 * lane;                   // cells of this lane's vector that exist
+    if (left >= 4) {
+        st4(p + 4 * lane, y);
+    } else if (left > 0) {
+        st1(p + 4 * lane, y.x);
+        if (left > 1) st1(p + 4 * lane + 1, y.y);
+        if (left > 2) st1(p + 4 * lane + 2, y.z);
+    }
+}
+
 // (A block that walks eight rows and loads the next row's velocity ahead of the current row's taps was measured slower:
 // 324 against 294 us at 8192^2.  The texture addresser is busy 94 % of k_advect2's time -- rocprofv3 TA_BUSY_avr --
 // so what these kernels wait for is the address path of their gathers, neither HBM nor latency.)
@@ -1145,32 +1182,33 @@ __global__ __launch_bounds__(256) void k_advect2(S* __restrict__ da, const S* __
                                                  const S* __restrict__ d0b, int bb, const S* __restrict__ u,
                                                  const S* __restrict__ v, int pitch, int n, int row_lo, int row_hi, float dt0)
 {
+    __shared__ __attribute__((aligned(16))) float tiles[4][2][256];
     const int j0 = advect_col0();
     const int i = row_lo + blockIdx.y;
     if (i >= row_hi) return;
     const IDX E = (IDX)sizeof(S), P = (IDX)pitch * E;
     const IDX r = (IDX)i * P + (IDX)XOFF * E;
     const bool wall = advect_wall_block(i, n);
+    const int wave = threadIdx.x >> 6;
+    const int c0 = j0 - (int)(threadIdx.x & 63);         // the wave's first column (wave-uniform)
+    const int cells = min(256, n + 1 - c0);              // how many of its 256 columns exist
+    if (cells <= 0) return;
     float uu[kAdvectRounds], vv[kAdvectRounds], va[kAdvectRounds], vb[kAdvectRounds];
-#pragma unroll
-    for (int k = 0; k < kAdvectRounds; ++k) {
-        const IDX c = r + (IDX)min(j0 + 64 * k, n) * E;
-        uu[k] = ld1(at(u, c));
-        vv[k] = ld1(at(v, c));
-    }
+    wave_cells_in(at(u, r + (IDX)c0 * E), cells, tiles[wave][0], uu);
+    wave_cells_in(at(v, r + (IDX)c0 * E), cells, tiles[wave][1], vv);
 #pragma unroll
     for (int k = 0; k < kAdvectRounds; ++k) {
         const AdvectTap<IDX> t = advect_trace<IDX>(min(j0 + 64 * k, n), i, uu[k], vv[k], dt0, n, P, E);
         va[k] = advect_sample(d0a, P, t);
         vb[k] = advect_sample(d0b, P, t);
     }
+    wave_cells_out(at(da, r + (IDX)c0 * E), cells, tiles[wave][0], va);
+    wave_cells_out(at(db, r + (IDX)c0 * E), cells, tiles[wave][1], vb);
+    if (wall) {
 #pragma unroll
-    for (int k = 0; k < kAdvectRounds; ++k) {
-        const int j = j0 + 64 * k;
-        if (j <= n) {
-            st1(at(da, r + (IDX)j * E), va[k]);
-            st1(at(db, r + (IDX)j * E), vb[k]);
-            if (wall) {
+        for (int k = 0; k < kAdvectRounds; ++k) {
+            const int j = j0 + 64 * k;
+            if (j <= n) {
                 emit_ghosts(da, (size_t)pitch, n, ba, j, i, va[k]);
                 emit_ghosts(db, (size_t)pitch, n, bb, j, i, vb[k]);
             }
