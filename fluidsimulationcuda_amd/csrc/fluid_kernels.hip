@@ -1149,27 +1149,28 @@ __global__ __launch_bounds__(256) void k_advect(S* __restrict__ d, const S* __re
                                                 const S* __restrict__ v, int pitch, int n, int row_lo, int row_hi,
                                                 float dt0, int b)
 {
+    __shared__ __attribute__((aligned(16))) float tiles[4][2][256];
     const int j0 = advect_col0();
     const int i = row_lo + blockIdx.y;
     if (i >= row_hi) return;
     const IDX E = (IDX)sizeof(S), P = (IDX)pitch * E;
     const IDX r = (IDX)i * P + (IDX)XOFF * E;
     const bool wall = advect_wall_block(i, n);
+    const int wave = threadIdx.x >> 6;
+    const int c0 = j0 - (int)(threadIdx.x & 63);         // the wave's first column (wave-uniform)
+    const int cells = min(256, n + 1 - c0);              // how many of its 256 columns exist
+    if (cells <= 0) return;
     float uu[kAdvectRounds], vv[kAdvectRounds], val[kAdvectRounds];
-#pragma unroll
-    for (int k = 0; k < kAdvectRounds; ++k) {
-        const IDX c = r + (IDX)min(j0 + 64 * k, n) * E;  // lanes past the row's end repeat its last cell (and store nothing)
-        uu[k] = ld1(at(u, c));
-        vv[k] = ld1(at(v, c));
-    }
+    wave_cells_in(at(u, r + (IDX)c0 * E), cells, tiles[wave][0], uu);
+    wave_cells_in(at(v, r + (IDX)c0 * E), cells, tiles[wave][1], vv);
 #pragma unroll
     for (int k = 0; k < kAdvectRounds; ++k) val[k] = advect_sample(d0, P, advect_trace<IDX>(min(j0 + 64 * k, n), i, uu[k], vv[k], dt0, n, P, E));
+    wave_cells_out(at(d, r + (IDX)c0 * E), cells, tiles[wave][0], val);
+    if (wall) {
 #pragma unroll
-    for (int k = 0; k < kAdvectRounds; ++k) {
-        const int j = j0 + 64 * k;
-        if (j <= n) {
-            st1(at(d, r + (IDX)j * E), val[k]);
-            if (wall) emit_ghosts(d, (size_t)pitch, n, b, j, i, val[k]);
+        for (int k = 0; k < kAdvectRounds; ++k) {
+            const int j = j0 + 64 * k;
+            if (j <= n) emit_ghosts(d, (size_t)pitch, n, b, j, i, val[k]);
         }
     }
 }
