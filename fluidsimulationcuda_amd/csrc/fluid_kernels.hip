@@ -1033,10 +1033,11 @@ __global__ __launch_bounds__(256) void k_tile_min_abs(TileBatch tb, int pitch, i
 // What bounds these kernels is the gather, not HBM: a wave-wide load whose lanes are 16 bytes apart touches eight
 // 128-byte lines to use a quarter of each, and a cell needs four taps per advected field.  So a wave works on 256
 // consecutive cells of a row in four rounds of 64 -- lane l takes cells l, 64+l, 128+l, 192+l -- which makes every
-// access of every round lane-contiguous: velocities in and results out as one dword per lane (256 bytes per wave
-// instruction, whole lines), and the two horizontally adjacent taps of a cell as ONE 8-byte load (they are contiguous
-// in memory; 4-byte aligned, which global loads allow), so a round's taps touch three lines per instruction, not
-// eight.  Four independent back-traces per thread keep 8 or 16 loads in flight.  Per cell the arithmetic is the
+// gather of every round lane-contiguous: the two horizontally adjacent taps of a cell are ONE 8-byte load (they are
+// contiguous in memory; 4-byte aligned, which global loads allow), so a round's taps touch three lines per instruction,
+// not eight.  The wave's own cells -- velocities in, results out -- travel as one 16-byte access per lane and change
+// into that order through LDS (wave_cells_in / wave_cells_out; k_gradient_advect keeps one dword per lane and round,
+// see there).  Four independent back-traces per thread keep 8 or 16 loads in flight.  Per cell the arithmetic is the
 // reference's, in its order.
 // Offsets are BYTE offsets of type IDX: unsigned for fields below 2^32 bytes (every size up to ~32700^2 fp32), so an
 // access is a scalar base plus a 32-bit vector offset and no 64-bit vector arithmetic is spent on addresses; size_t beyond.
