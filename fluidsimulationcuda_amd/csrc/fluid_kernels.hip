@@ -1325,6 +1325,8 @@ __global__ __launch_bounds__(256) void k_max_partials(const float* __restrict__ 
 // back-trace of cell (i, j) needs u and v at (i, j) only -- the values this thread holds in registers
 // (as stored: rounded to the storage type first) -- so the advection need not read the two fields back.
 // Four cells per thread (64 apart, as in k_advect), per cell the arithmetic of k_subtract_gradient and k_advect.
+// (Its own cells move as one dword per lane and round: the 16-byte accesses through LDS that pay in k_advect2 -- 44 -> 18
+// memory instructions per wave and row here -- were built and measured for this kernel too, and gained nothing.)
 template <typename S, typename IDX>
 __global__ __launch_bounds__(256) void k_gradient_advect(S* __restrict__ u, S* __restrict__ v, const S* __restrict__ p,
                                                          S* __restrict__ d, const S* __restrict__ d0, int pitch, int n,
