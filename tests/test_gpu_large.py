@@ -204,3 +204,53 @@ def test_40_sweep_solve_at_16384_fp32_matches_windowed_oracle(F, oracle, form):
         assert a1 > a0 and c1 > c0
         assert_bit_equal(got[i0 + a0:i0 + a1, j0 + c0:j0 + c1], xw[a0:a1, c0:c1],
                          "%s solve at 16384^2, window at (%d, %d)" % (form, i0, j0))
+
+
+def test_two_steps_at_8192_on_eight_slabs_match_one_context(F):
+    """BASELINE config 3 as the driver's scaling run splits it -- 8192^2 over EIGHT row slabs (1023 or 1024 rows each,
+    default ghost zones, density diffusion on the second stream, advections started on the previous bound) -- here as
+    eight contexts on this one GPU behind the in-process fabric, against one context: every bit of u, v and dens after
+    the sourced step and a plain one, and the same exchange sequence on every rank."""
+    from test_gpu_slab import run_ranks
+    from fluidsimulationcuda_amd.harness import initialize_parameters
+    n = 8190
+    f = initialize_parameters(n, seed=8)
+
+    def body(s):
+        s.step(1, use_sources=True)
+        s.step(1)
+
+    with F.FluidSolver(n) as s:
+        s.upload(**f)
+        body(s)
+        one = {k: s.download(k) for k in ("u", "v", "dens")}
+    got, fab = run_ranks(n, 8, 0, f, body, jacobi=3)
+    for r in range(1, 8):
+        assert fab.log[r] == fab.log[0]
+    for k in ("u", "v", "dens"):
+        assert_bit_equal(got[k], one[k], "%s: 8 slabs vs one context at 8192^2" % k)
+
+
+def test_two_steps_at_16384_fp16_on_eight_slabs_match_one_context(F):
+    """BASELINE config 4 with its own split: 16384^2, fp16 storage, EIGHT row slabs (in-process fabric, one GPU) against
+    one context -- with fp16 storage every launch rounds once, so this also pins that eight slabs and one GPU take the
+    same launch schedule."""
+    from test_gpu_slab import run_ranks
+    from fluidsimulationcuda_amd import capi
+    from fluidsimulationcuda_amd.harness import initialize_parameters
+    n = 16382
+    f = initialize_parameters(n, seed=9)
+
+    def body(s):
+        s.step(1, use_sources=True)
+        s.step(1)
+
+    with F.FluidSolver(n, storage=capi.STORAGE_F16) as s:
+        s.upload(**f)
+        body(s)
+        one = {k: s.download(k) for k in ("u", "v", "dens")}
+    got, fab = run_ranks(n, 8, 0, f, body, jacobi=3, storage=capi.STORAGE_F16)
+    for r in range(1, 8):
+        assert fab.log[r] == fab.log[0]
+    for k in ("u", "v", "dens"):
+        assert_bit_equal(got[k], one[k], "%s: 8 slabs vs one context at 16384^2, fp16 storage" % k)
