@@ -183,9 +183,34 @@ def checksums():
         json.dump(rows, f, indent=1)
 
 
+def trajectory_checksums():
+    """The reference's own loop over several steps (FluidSequential.c:289-324: sources at step 0 only, zeroed before every
+    later step) at the grids where arrays are too big to commit: CRC-32 of u, v and dens after EVERY step, so that the
+    decay of the fields towards zero is pinned to the reference itself, not only its first step."""
+    import json
+    import zlib
+    rows = []
+    for n, steps in ((1022, 10), (4094, 5)):
+        r = Reference(n, 40)
+        dens, dens0, u, u0, v, v0 = r.initialize(seed=1)
+        for z in range(1, steps + 1):
+            if z == 1:
+                r.step_src(u, v, dens, u0, v0, dens0)
+            else:
+                r.step(u, v, dens, u0, v0, dens0)
+            rows.append(dict(n=n, step=z, crc_u=zlib.crc32(u.view(np.uint8).reshape(-1)), crc_v=zlib.crc32(v.view(np.uint8).reshape(-1)),
+                             crc_dens=zlib.crc32(dens.view(np.uint8).reshape(-1)), max_u=float(np.abs(u).max())))
+            print(rows[-1])
+    with open(os.path.join(OUT, "trajectory_checksums.json"), "w") as f:
+        json.dump(rows, f, indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["checksums"]:
         checksums()
+        sys.exit(0)
+    if sys.argv[1:] == ["trajectory"]:
+        trajectory_checksums()
         sys.exit(0)
     if sys.argv[1:] == ["state_grid"]:
         state_grid()
@@ -197,4 +222,5 @@ if __name__ == "__main__":
     full_steps(126, iters=20, steps=(1, 2))
     state_grid()
     checksums()
+    trajectory_checksums()
     print("golden vectors written to", OUT)

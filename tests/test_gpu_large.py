@@ -254,3 +254,19 @@ def test_two_steps_at_16384_fp16_on_eight_slabs_match_one_context(F):
         assert fab.log[r] == fab.log[0]
     for k in ("u", "v", "dens"):
         assert_bit_equal(got[k], one[k], "%s: 8 slabs vs one context at 16384^2, fp16 storage" % k)
+
+
+@pytest.mark.parametrize("n", [1022, 4094])
+def test_reference_trajectory_crc(F, n):
+    """The reference's own loop over 10 (N = 1022) / 5 (N = 4094) steps -- sources at step 0 only, fields decaying by one
+    to two orders of magnitude per step -- as the compiled reference ran it (tests/golden/trajectory_checksums.json,
+    make_golden.py trajectory): CRC-32 of u, v and dens after every single step, device-resident throughout."""
+    from oracle.oracle import Oracle
+    rows = [r for r in json.load(open(os.path.join(GOLDEN, "trajectory_checksums.json"))) if r["n"] == n]
+    dens, dens0, u, u0, v, v0 = Oracle().initialize_glibc(n, seed=1)
+    with F.FluidSolver(n) as s:
+        s.upload(u=u, v=v, dens=dens, u_prev=u0, v_prev=v0, dens_prev=dens0)
+        for row in rows:
+            s.step(1, use_sources=row["step"] == 1)
+            got = tuple(crc(s.download(k)) for k in ("u", "v", "dens"))
+            assert got == (row["crc_u"], row["crc_v"], row["crc_dens"]), "N=%d, step %d" % (n, row["step"])

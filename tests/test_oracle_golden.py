@@ -101,6 +101,23 @@ def test_checksums_survey_values(oracle):
     assert abs(float(g["s1_dens"].sum(dtype=np.float64)) - 35.0967363) < 1e-6
 
 
+def test_trajectory_checksums_at_1022(oracle):
+    """The reference's loop over ten steps at N = 1022 (sources at step 0 only; the fields decay through five orders of
+    magnitude): the restatement reproduces the CRC-32 of u, v and dens the compiled reference left after every step
+    (tests/golden/trajectory_checksums.json; the GPU follows the same file, and N = 4094, in test_gpu_large.py)."""
+    import zlib
+    rows = [r for r in json.load(open(os.path.join(GOLDEN, "trajectory_checksums.json"))) if r["n"] == 1022]
+    assert [r["step"] for r in rows] == list(range(1, 11))
+    dens, dens0, u, u0, v, v0 = oracle.initialize_glibc(1022, seed=1)
+    for row in rows:
+        if row["step"] == 1:
+            oracle.step_src(u, v, dens, u0, v0, dens0)
+        else:
+            oracle.step(u, v, dens, u0, v0, dens0)
+        for name, a in (("u", u), ("v", v), ("dens", dens)):
+            assert zlib.crc32(a.view(np.uint8).reshape(-1)) == row["crc_" + name], "%s after step %d" % (name, row["step"])
+
+
 def test_odd_and_zero_sweeps(oracle):
     """The restatement accepts an odd count (result copied back) -- the ABI
     rejects it; zero sweeps leaves x untouched."""
