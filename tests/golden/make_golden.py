@@ -190,7 +190,7 @@ def trajectory_checksums():
     import json
     import zlib
     rows = []
-    for n, steps in ((1022, 10), (4094, 5)):
+    for n, steps in ((1022, 10), (4094, 5), (8190, 3)):
         r = Reference(n, 40)
         dens, dens0, u, u0, v, v0 = r.initialize(seed=1)
         for z in range(1, steps + 1):

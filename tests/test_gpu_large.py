@@ -256,9 +256,9 @@ def test_two_steps_at_16384_fp16_on_eight_slabs_match_one_context(F):
         assert_bit_equal(got[k], one[k], "%s: 8 slabs vs one context at 16384^2, fp16 storage" % k)
 
 
-@pytest.mark.parametrize("n", [1022, 4094])
+@pytest.mark.parametrize("n", [1022, 4094, 8190])
 def test_reference_trajectory_crc(F, n):
-    """The reference's own loop over 10 (N = 1022) / 5 (N = 4094) steps -- sources at step 0 only, fields decaying by one
+    """The reference's own loop over 10 (N = 1022) / 5 (N = 4094) / 3 (N = 8190) steps -- sources at step 0 only, fields decaying by one
     to two orders of magnitude per step -- as the compiled reference ran it (tests/golden/trajectory_checksums.json,
     make_golden.py trajectory): CRC-32 of u, v and dens after every single step, device-resident throughout."""
     from oracle.oracle import Oracle
