@@ -2,7 +2,11 @@
 """bench.py -- BASELINE.json's metric on MI355X: Mcells/s per Jacobi iteration
 and ms per simulation step of the Stable-Fluids vel_step + dens_step.
 
-  python bench.py [--gpus N --steps K --warmup W]      (N>1: under torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W]
+
+With N > 1 and no WORLD_SIZE in the environment the command starts its own N ranks as child processes
+(python -m torch.distributed.run ... bench.py, before anything here touches the GPU) and relays rank 0's line;
+started under torch.distributed.run (as the driver does) it is one of those ranks.
 
 `value` follows SURVEY.md 8(d): W^2 / t_sweep with t_sweep the mean time of one sweep (set_bnd included) of the
 40-sweep pressure solves (alpha 1, beta 4, b 0) inside the timed steps, HIP events on the solver's stream;
@@ -14,9 +18,11 @@ sources zeroed, vel_step, dens_step, 40 Jacobi sweeps per solve = 200 sweeps,
 starts.  One JSON line on rank 0.
 
 Workload: N=1 -> 4096^2 (the grid BASELINE.json's metric is quoted on, config
-2); N>1 -> 8192^2 split into row slabs (config 3), strong scaling.  The N=1
-line also carries the 1-GPU 8192^2 measurement ("scaling_base") so the 8192^2
-speed-up can be formed from the driver's own runs.
+2); N>1 -> 8192^2 split into row slabs (config 3), strong scaling, with the
+4096^2 grid on the same slabs beside it ("grid_4096": north_star asks for both
+grids at 1/2/4/8 GPUs).  The N=1 line carries the 1-GPU 8192^2 measurement
+("scaling_base"), the N>1 line rank 0's own 1-GPU run of both grids
+("single_gpu"), so either speed-up can be formed from one line.
 
 Two data regimes are reported.  The headline follows the reference's loop: sources only at step 0, zeroed
 afterwards (FluidSequential.c:298-302), so every solve restarts from a zero first guess and the fields decay
@@ -60,7 +66,9 @@ def parse():
     ap.add_argument("--t16-min-cells", type=int, default=-1, help="FLUID_PARAM_TB_T16_MIN_CELLS (default: library's rule)")
     ap.add_argument("--halo", type=int, default=0, help="multi-GPU ghost-zone depth (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-scaling-base", action="store_true")
+    ap.add_argument("--no-scaling-base", action="store_true", help="skip the other side of the speed-up (N=1: the 8192^2 run; "
+                                                                   "N>1: rank 0's single-GPU runs)")
+    ap.add_argument("--no-second-grid", action="store_true", help="N>1: skip the 4096^2 leg")
     ap.add_argument("--no-ordinary", action="store_true", help="skip the value_ordinary_data leg")
     ap.add_argument("--only-ordinary", action="store_true", help="profiling aid: run only the ordinary-data leg")
     ap.add_argument("--seed", type=int, default=1)
@@ -174,7 +182,7 @@ def pmc_per_launch(summary, kernel, key):
     """Mean of `key` per launch over all instantiations of `kernel`, weighted by how often each ran."""
     tot = cnt = 0.0
     for name, v in summary.items():
-        if name.split("<")[0] != kernel or not v.get(key):
+        if not isinstance(v, dict) or name.split("<")[0] != kernel or not v.get(key):
             continue
         tot += v[key] * v["launches_sampled"]
         cnt += v["launches_sampled"]
@@ -227,8 +235,39 @@ def cpu_baseline(n, fields, iters):
     return out
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` as typed: N ranks as CHILD processes (python -m torch.distributed.run, one per GPU, RCCL
+    rendezvous on 127.0.0.1), started before this process has imported torch or touched the GPU -- never a re-exec of a
+    process that has.  The children inherit stdout / stderr, so rank 0's JSON line is this command's output; the exit
+    status is the launcher's."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+
+
+def library_source_hash():
+    """sha256 over the sources libfluid_amd.so is built from (csrc/*.hip, *.h, Makefile, include/fluid_amd.h): what ties a
+    committed PMC summary to the kernels it measured (tools/summarize_profiles.py stores the same hash)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "fluidsimulationcuda_amd", "csrc")
+    names = sorted(f for f in os.listdir(src) if f.endswith((".hip", ".h")) or f == "Makefile")
+    for f in [os.path.join(src, x) for x in names] + [os.path.join(ROOT, "include", "fluid_amd.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(a))
     # stdout carries ONE line, the JSON: libraries that write to file descriptor 1 themselves (RCCL prints its host name
     # and library path there when a communicator comes up) go to stderr until that line is due
     sys.stdout.flush()
@@ -247,10 +286,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
-        a.gpus = world
+    a.gpus = world                                          # under a launcher the launcher's world size is the truth
     local = local % max(torch.cuda.device_count(), 1)       # rehearsal: several ranks may share a GPU
     torch.cuda.set_device(local)
     if world > 1:
@@ -296,7 +332,7 @@ def main():
         (FLUID_PARAM_TB_AUTOTUNE) and keeps the result for the process: let it finish in a throw-away context so that
         neither the warm-up nor the timed steps contain trial launches.  Not counted as steps; the same number of
         steps on every rank (a step holds collectives)."""
-        if a.variant != 3 or a.tb_rows or n_ in tuning:
+        if a.variant != 3 or a.tb_rows or (n_, world) in tuning:
             return
         s = make(n_)
         s.load_global(**initialize_parameters(n_, seed=a.seed))
@@ -310,7 +346,7 @@ def main():
             s.synchronize()
             if world == 1 and s.autotune_pending() == 0:
                 break
-        tuning[n_] = {"untimed_steps": steps, "shapes_still_open": s.autotune_pending()}
+        tuning[(n_, world)] = {"untimed_steps": steps, "shapes_still_open": s.autotune_pending()}
         s.close()
 
     def run(n_, steps, warmup, fuse_divergence=True):
@@ -371,21 +407,124 @@ def main():
                     sys.exit("rank %d: %s differs between %d slabs and one context" % (rank, k, world))
         if rank == 0:
             print("check ok: %d slabs bit-identical to one context at %dx%d" % (world, grid, grid), file=sys.stderr)
-    (elapsed, jac_ms, prs_ms, t, solve), fields, calls = run(n, a.steps, a.warmup)
-    r = rates(elapsed, jac_ms, prs_ms, t, a.steps, cells, solve)
-    ms_step, t_sweep = r["ms_per_step"], r["t_sweep"]
-    native_exchange = native[0]
-    sweeps, field_launches = t["sweeps"], t["jacobi_field_launches"]
-    bpc = BYTES_PER_CELL_SWEEP // (2 if a.dtype == "f16" else 1)
-    achieved = bpc * cells / t_sweep / 1e9
-    launches = max(t["jacobi_launches"], 1)
-    per_launch = sweeps / launches                       # field-sweeps per launch (a batched launch sweeps 3 fields)
-    kernel_name = ("k_jacobi_tb (8, 12 or 16 sweeps + set_bnd per launch, up to 3 fields per launch; %.1f launches/step)"
-                   % (launches / a.steps)) if a.variant == 3 else "k_jacobi_%s (one sweep + fused set_bnd)" % KERNELS[a.variant]
+    def measure_grid(grid_, steps, warmup):
+        """One grid on this job's ranks: the timed steps, the rates and the roofline objects."""
+        n_, cells_ = grid_ - 2, grid_ * grid_
+        (elapsed, jac_ms, prs_ms, t, solve), fields, calls = run(n_, steps, warmup)
+        r = rates(elapsed, jac_ms, prs_ms, t, steps, cells_, solve)
+        ms_step, t_sweep = r["ms_per_step"], r["t_sweep"]
+        sweeps, field_launches = t["sweeps"], t["jacobi_field_launches"]
+        bpc = BYTES_PER_CELL_SWEEP // (2 if a.dtype == "f16" else 1)
+        achieved = bpc * cells_ / t_sweep / 1e9
+        launches = max(t["jacobi_launches"], 1)
+        per_launch = sweeps / launches                       # field-sweeps per launch (a batched launch sweeps 3 fields)
+        kernel_name = ("k_jacobi_tb (8, 12 or 16 sweeps + set_bnd per launch, up to 3 fields per launch; %.1f launches/step)"
+                       % (launches / steps)) if a.variant == 3 else "k_jacobi_%s (one sweep + fused set_bnd)" % KERNELS[a.variant]
+        out = {
+            "value": r["value"], "unit": "Mcells/s", "ms_per_step": ms_step, "steps": steps, "warmup": warmup,
+            "kernel_ms_per_step": dict(r["kernel_ms_per_step"], note="HIP events per operator category (the reference's timers, "
+                                       "FluidSequential.c:192-234); 'projection' holds the gradient subtractions, the second "
+                                       "one fused with the density advection"),
+            "us_per_jacobi_sweep": r["us_per_jacobi_sweep"],
+            "value_definition": ("SURVEY.md 8(d)(i): W^2 / t_sweep over the 40-sweep pressure solve (alpha 1, beta 4, b 0, first guess 0), "
+                                 "%d solves on the fields the timed steps left behind, HIP events around each solve; the divergence "
+                                 "before it is a kernel of its own there" % (solve[1] // a.iters)) if solve else
+                                "W^2 / t_sweep over the pressure solves inside the timed steps (HIP events, max over ranks)",
+            "in_step_pressure_solve": {"us_per_jacobi_sweep": r["in_step_pressure_us_per_sweep"],
+                                       "value": cells_ / (r["in_step_pressure_us_per_sweep"] * 1e-6) / 1e6,
+                                       "note": "the 80 pressure sweeps of each timed step; their first launch also computes "
+                                               "and stores the projection's divergence (no separate k_divergence pass), so this is "
+                                               "sweeps + divergence"},
+            "all_solves": {"value": r["all_solves_value"], "unit": "Mcells/s", "us_per_jacobi_sweep": t_sweep * 1e6,
+                           "note": "the same rate over all 200 sweeps of the step (3 diffusions, whose exact division "
+                                   "by 1+4a costs more than the pressure solve's multiply by 1/4, + 2 pressure solves)"},
+            "step_algorithmic_GBps": BYTES_PER_CELL_STEP // (2 if a.dtype == "f16" else 1) * cells_ / (ms_step * 1e-3) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": kernel_name,
+                         "achieved": achieved * (1.0 / world), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / world / HBM_PEAK_GBS, "traffic": None,
+                         "launches": launches, "mean_launch_us": jac_ms * 1e3 / launches,
+                         "algorithmic_bytes_per_launch": bpc * (cells_ // world) * per_launch,
+                         "note": ("SURVEY.md 8(d)'s definition -- per GPU: algorithmic 12 B/cell/sweep x %d cells x %.1f "
+                                  "field-sweeps per launch / mean launch time, HIP events on the solver's stream over %d "
+                                  "timed launches" % (cells_ // world, per_launch, launches)) + (
+                                     ".  Temporal blocking keeps the intermediate sweeps on chip, so this ALGORITHMIC rate "
+                                     "exceeds the HBM peak and `frac` is not a fraction of anything the hardware does: "
+                                     "`frac_compulsory` prices each launch at its own compulsory traffic (read x, x0, "
+                                     "write x once per field = 12 B/cell), and `roofline_actual` states what the launches "
+                                     "are bound by and how close they come (<= 1)" if a.variant == 3 else "")},
+        }
+        out["roofline"]["frac_compulsory"] = bpc * (cells_ / world) * field_launches / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        pmc = pmc_summary(grid_) if world == 1 else None
+        if pmc:
+            summary, src = pmc
+            stale = summary.get("_source_sha256") != library_source_hash()
+            kern = "k_jacobi_%s" % KERNELS[a.variant]
+            traffic = pmc_per_launch(summary, kern, "hbm_bytes_per_launch")
+            valu = pmc_per_launch(summary, kern, "valu_insts_per_launch")
+            mean_us = jac_ms * 1e3 / launches
+            if stale:
+                out["roofline"]["stale_profile"] = True
+                out["roofline"]["traffic_note"] = ("profiles/%s was taken from other kernel sources than the library loaded "
+                                                   "here (its _source_sha256 differs): counters not used" % src)
+            elif traffic:
+                out["roofline"]["traffic"] = traffic
+                out["roofline"]["traffic_source"] = "profiles/" + src
+            if traffic and valu and not stale:
+                hbm_frac = traffic / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                valu_rate = valu / SIMDS / mean_us
+                valu_frac = valu_rate / VALU_PEAK_PER_SIMD_US
+                out["roofline_actual"] = {
+                    "bound": "valu_issue" if valu_frac >= hbm_frac else "hbm",
+                    "achieved": valu_rate if valu_frac >= hbm_frac else traffic / (mean_us * 1e-6) / 1e9,
+                    "peak": VALU_PEAK_PER_SIMD_US if valu_frac >= hbm_frac else HBM_PEAK_GBS,
+                    "unit": "wave-instructions/us/SIMD" if valu_frac >= hbm_frac else "GB/s",
+                    "frac": max(valu_frac, hbm_frac),
+                    "valu_issue": {"achieved": valu_rate, "peak": VALU_PEAK_PER_SIMD_US, "frac": valu_frac,
+                                   "valu_insts_per_launch": valu},
+                    "hbm": {"achieved": traffic / (mean_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "frac": hbm_frac,
+                            "bytes_per_launch": traffic},
+                    "note": "mean Jacobi launch of the timed steps (HIP events) against both ceilings: vector instructions per "
+                            "launch (SQ_INSTS_VALU) over the 1024 SIMDs vs what one SIMD sustains of this instruction mix "
+                            "(tools/ubench/valu_peak.hip), and HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) vs the 8 TB/s "
+                            "peak; counters from %s (the same command under rocprofv3, one --pmc pass per counter group; "
+                            "its source hash matches the library loaded here)" % ("profiles/" + src)}
+        elif world > 1:
+            out["roofline"]["traffic_note"] = ("no PMC summary exists for slab launches (this pool hands out one GPU per call): "
+                                               "frac_compulsory is the measured figure, roofline_actual is given for 1 GPU only")
+        if (n_, world) in tuning:
+            out["autotune"] = dict(tuning[(n_, world)], note="strip heights of the fused Jacobi kernel measured by the library in a throw-away "
+                                   "context before the warm-up (FLUID_PARAM_TB_AUTOTUNE); results do not depend on them")
+        if calls:
+            out["exchanges_per_rank"] = {"halo": calls[0], "gather": calls[1], "max": calls[2],
+                                         "per_step": {"halo": calls[0] / (steps + warmup), "max": calls[2] / (steps + warmup)}}
+        if world > 1:
+            out["native_exchange"] = bool(native[0])
+        return out, fields, (elapsed, jac_ms, prs_ms, t)
+
+    def single_gpu(grid_, steps, warmup):
+        """rank 0 of a multi-GPU job, alone: the same grid in one context on its GPU (no collectives inside)."""
+        nonlocal world
+        keep, world = world, 1
+        try:
+            tune(grid_ - 2)
+            s = make(grid_ - 2)
+            s.load_global(**initialize_parameters(grid_ - 2, seed=a.seed))
+            e, j, p, t = measure(s, None, 1, steps, warmup, a.iters)
+            s.close()
+            r = rates(e, j, p, t, steps, grid_ * grid_)
+            return {"ms_per_step": r["ms_per_step"], "in_step_pressure_value": r["value"], "all_solves_value": r["all_solves_value"],
+                    "steps": steps, "warmup": warmup}
+        except Exception as exc:                         # a courtesy figure: never fails the line
+            return {"error": repr(exc)}
+        finally:
+            world = keep
+
+    m, fields, _raw = measure_grid(grid, a.steps, a.warmup)
     arith = "fp32" if a.dtype == "f32" else "fp16 storage, fp32 arithmetic"
+    native_exchange = native[0]
     line = {
-        "metric": "Mcells/s per Jacobi iter", "value": r["value"], "unit": "Mcells/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+        "metric": "Mcells/s per Jacobi iter", "value": m["value"], "unit": "Mcells/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": m["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32" if a.dtype == "f32" else "f16 storage, f32 arithmetic",
         "data": "synthetic (initializeParameters recipe, PCG64 seed %d; sources at step 0 only, as the reference's loop: "
@@ -396,71 +535,30 @@ def main():
                    "parallelism": "1 GPU" if world == 1 else "row slabs x%d, halo rows by %s" % (
                        world, "RCCL, library-native exchange (csrc/fluid_exchange_rccl.hip)" if native_exchange else
                        "RCCL via torch.distributed" if a.backend == "nccl" else a.backend + " (host-staged rehearsal)")},
-        "ms_per_sim_step": ms_step,
-        "kernel_ms_per_step": dict(r["kernel_ms_per_step"], note="HIP events per operator category (the reference's timers, "
-                                   "FluidSequential.c:192-234); 'projection' holds the gradient subtractions, the second "
-                                   "one fused with the density advection"),
-        "us_per_jacobi_sweep": r["us_per_jacobi_sweep"],
-        "value_definition": ("SURVEY.md 8(d)(i): W^2 / t_sweep over the 40-sweep pressure solve (alpha 1, beta 4, b 0, first guess 0), "
-                             "%d solves on the fields the timed steps left behind, HIP events around each solve; the divergence "
-                             "before it is a kernel of its own there" % (solve[1] // a.iters)) if solve else
-                            "W^2 / t_sweep over the pressure solves inside the timed steps (HIP events)",
-        "in_step_pressure_solve": {"us_per_jacobi_sweep": r["in_step_pressure_us_per_sweep"],
-                                   "value": cells / (r["in_step_pressure_us_per_sweep"] * 1e-6) / 1e6,
-                                   "note": "the 80 pressure sweeps of each timed step; on one GPU their first launch also computes "
-                                           "and stores the projection's divergence (no separate k_divergence pass), so this is "
-                                           "sweeps + divergence"},
-        "all_solves": {"value": r["all_solves_value"], "unit": "Mcells/s", "us_per_jacobi_sweep": t_sweep * 1e6,
-                       "note": "the same rate over all 200 sweeps of the step (3 diffusions, whose exact division "
-                               "by 1+4a costs more than the pressure solve's multiply by 1/4, + 2 pressure solves)"},
-        "step_algorithmic_GBps": BYTES_PER_CELL_STEP // (2 if a.dtype == "f16" else 1) * cells / (ms_step * 1e-3) / 1e9,
-        "roofline": {"bound": "hbm", "kernel": kernel_name,
-                     "achieved": achieved * (1.0 / world), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / world / HBM_PEAK_GBS, "traffic": None,
-                     "launches": launches, "mean_launch_us": jac_ms * 1e3 / launches,
-                     "algorithmic_bytes_per_launch": bpc * (cells // world) * per_launch,
-                     "note": ("SURVEY.md 8(d)'s definition -- per GPU: algorithmic 12 B/cell/sweep x %d cells x %.1f "
-                              "field-sweeps per launch / mean launch time, HIP events on the solver's stream over %d "
-                              "timed launches" % (cells // world, per_launch, launches)) + (
-                                 ".  Temporal blocking keeps the intermediate sweeps on chip, so this ALGORITHMIC rate "
-                                 "exceeds the HBM peak and `frac` is not a fraction of anything the hardware does: "
-                                 "`frac_compulsory` prices each launch at its own compulsory traffic (read x, x0, "
-                                 "write x once per field = 12 B/cell), and `roofline_actual` states what the launches "
-                                 "are bound by and how close they come (<= 1)" if a.variant == 3 else "")},
+        "ms_per_sim_step": m["ms_per_step"],
     }
-    line["roofline"]["frac_compulsory"] = bpc * (cells / world) * field_launches / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-    pmc = pmc_summary(grid) if world == 1 else None
-    if pmc:
-        summary, src = pmc
-        kern = "k_jacobi_%s" % KERNELS[a.variant]
-        traffic = pmc_per_launch(summary, kern, "hbm_bytes_per_launch")
-        valu = pmc_per_launch(summary, kern, "valu_insts_per_launch")
-        mean_us = jac_ms * 1e3 / launches
-        if traffic:
-            line["roofline"]["traffic"] = traffic
-            line["roofline"]["traffic_source"] = "profiles/" + src
-        if traffic and valu:
-            hbm_frac = traffic / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS
-            valu_rate = valu / SIMDS / mean_us
-            valu_frac = valu_rate / VALU_PEAK_PER_SIMD_US
-            line["roofline_actual"] = {
-                "bound": "valu_issue" if valu_frac >= hbm_frac else "hbm",
-                "achieved": valu_rate if valu_frac >= hbm_frac else traffic / (mean_us * 1e-6) / 1e9,
-                "peak": VALU_PEAK_PER_SIMD_US if valu_frac >= hbm_frac else HBM_PEAK_GBS,
-                "unit": "wave-instructions/us/SIMD" if valu_frac >= hbm_frac else "GB/s",
-                "frac": max(valu_frac, hbm_frac),
-                "valu_issue": {"achieved": valu_rate, "peak": VALU_PEAK_PER_SIMD_US, "frac": valu_frac,
-                               "valu_insts_per_launch": valu},
-                "hbm": {"achieved": traffic / (mean_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "frac": hbm_frac,
-                        "bytes_per_launch": traffic},
-                "note": "mean Jacobi launch of the timed steps (HIP events) against both ceilings: vector instructions per "
-                        "launch (SQ_INSTS_VALU) over the 1024 SIMDs vs what one SIMD sustains of this instruction mix "
-                        "(tools/ubench/valu_peak.hip), and HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) vs the 8 TB/s "
-                        "peak; counters from %s (the same command under rocprofv3, one --pmc pass per counter group)"
-                        % ("profiles/" + src)}
-    if tuning:
-        line["autotune"] = dict(tuning[n], note="strip heights of the fused Jacobi kernel measured by the library in a throw-away "
-                                "context before the warm-up (FLUID_PARAM_TB_AUTOTUNE); results do not depend on them")
+    for k, v in m.items():
+        if k not in ("value", "unit", "ms_per_step", "steps", "warmup"):
+            line[k] = v
+    cells = grid * grid
+    bpc = BYTES_PER_CELL_SWEEP // (2 if a.dtype == "f16" else 1)
+    if world > 1 and grid != 4096 and not a.no_second_grid:
+        # north_star: "throughput on synthetic 4096^2 and 8192^2 grids is reported at 1/2/4/8 GPUs"; BASELINE.json's metric is
+        # quoted on 4096^2.  Same ranks, same code path, the other grid (strong scaling: 4096 / N rows per rank).
+        g2, _f2, _r2 = measure_grid(4096, a.steps, a.warmup)
+        line["grid_4096"] = dict(g2, workload="4096x4096 grid on the same %d row slabs" % world)
+    if world > 1 and not a.no_scaling_base:
+        if rank == 0:
+            line["single_gpu"] = {"note": "rank 0 alone, one context on its GPU, the reference's loop (in-step figures), while the "
+                                          "other ranks wait at the barrier below: the 1-GPU side of this line's speed-ups",
+                                  str(grid): single_gpu(grid, max(a.steps // 4, 3), 2)}
+            if "grid_4096" in line:
+                line["single_gpu"]["4096"] = single_gpu(4096, max(a.steps // 2, 3), 2)
+            for g_, sub in ((grid, line), (4096, line.get("grid_4096"))):
+                base = line["single_gpu"].get(str(g_), {})
+                if sub is not None and base.get("ms_per_step"):
+                    sub["speedup_vs_single_gpu"] = base["ms_per_step"] / sub["ms_per_step"]
+        dist.barrier()
     if world == 1 and a.variant == 3:
         # the round-1 form of the step, for comparison across rounds: every operator a launch of its own
         (e3, j3, p3, t3, _s3), _, _ = run(n, a.steps, a.warmup, fuse_divergence=False)
@@ -471,8 +569,6 @@ def main():
             "all_solves_value": r3["all_solves_value"], "kernel_ms_per_step": r3["kernel_ms_per_step"],
             "note": "FLUID_PARAM_FUSE_DIVERGENCE = 0: the same K steps with k_divergence as a separate pass, so that the "
                     "pressure solves inside the steps are sweeps alone (how round 1 measured `value`)"}
-    if calls:
-        line["exchanges_per_rank"] = {"halo": calls[0], "gather": calls[1], "max": calls[2]}
     if world == 1 and not a.no_ordinary:
         e2, j2, p2, t2, copy_ms, solve2 = run_ordinary(n, a.steps, a.warmup)
         r2 = rates(e2, j2, p2, t2, a.steps, cells, solve2)
@@ -490,6 +586,7 @@ def main():
         r2 = rates(e2, j2, p2, t2, steps2, 8192 * 8192, solve2)
         line["scaling_base"] = {"workload": "8192x8192 on 1 GPU", "value": r2["value"], "unit": "Mcells/s",
                                 "ms_per_step": r2["ms_per_step"], "all_solves_value": r2["all_solves_value"],
+                                "in_step_pressure_value": 8192 * 8192 / (r2["in_step_pressure_us_per_sweep"] * 1e-6) / 1e6,
                                 "roofline_frac": BYTES_PER_CELL_SWEEP * 8192 * 8192 / r2["t_sweep"] / 1e9 / HBM_PEAK_GBS,
                                 "frac_compulsory": BYTES_PER_CELL_SWEEP * 8192 * 8192 * t2["jacobi_field_launches"]
                                 / (j2 * 1e-3) / 1e9 / HBM_PEAK_GBS}

@@ -99,6 +99,7 @@ SIGNATURES = {
     "fluid_op_diffuse_tol": [_ctx, _i, _i, _i, _f, _f, _f, _i, _i, C.POINTER(_i), C.POINTER(_f)],
     "fluid_set_exchange": [_ctx, EXCHANGE_FN, C.c_void_p],
     "fluid_exchange_now": [_ctx, _i, C.POINTER(_i), _i, _i],
+    "fluid_rccl_available": [],
     "fluid_rccl_unique_id": [C.c_void_p, C.c_size_t],
     "fluid_exchange_rccl_attach": [_ctx, C.c_void_p, C.c_size_t],
     "fluid_exchange_rccl_attach_comm": [_ctx, C.c_void_p],

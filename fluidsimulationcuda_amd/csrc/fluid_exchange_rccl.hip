@@ -119,7 +119,9 @@ static int rccl_exchange(void* user, int kind, const int* fields, int nfields, i
     const size_t row_bytes = (size_t)c->pitch * c->esz;
     switch (kind) {
     case FLUID_XCHG_HALO: {
-        if (depth < 1 || depth > c->own1 - c->own0) return fail(FLUID_E_COMM, "halo depth %d does not fit the slab", depth);
+        // against the SHORTEST slab (ranks differ by a row when N does not divide evenly): the verdict must be the same on
+        // every rank, or the tall ranks enter the group while the short ones return
+        if (depth < 1 || depth > c->min_slab) return fail(FLUID_E_COMM, "halo depth %d does not fit the slabs (shortest: %d rows)", depth, c->min_slab);
         x->calls[0] += 1;
         for (int k = 0; k < nfields; ++k) TRY(zero_if_marked(c, fields[k]));
         NCCL_TRY(api, api->GroupStart());
@@ -225,6 +227,13 @@ static int attach(fluid_ctx* c, ncclComm_t comm, bool own)
 using namespace fluid_detail;
 
 extern "C" {
+
+int fluid_rccl_available(void)
+{
+    RcclApi* api = rccl_api();
+    if (!api->error.empty()) return fail(FLUID_E_COMM, "%s", api->error.c_str());
+    return FLUID_OK;
+}
 
 int fluid_rccl_unique_id(void* id, size_t bytes)
 {

@@ -1570,6 +1570,10 @@ int fluid_exchange_now(fluid_ctx* c, int kind, const int* fields, int nfields, i
     if (!c->xchg) return fail(FLUID_E_COMM, "no exchange installed");
     if (kind != FLUID_XCHG_HALO && kind != FLUID_XCHG_GATHER) return fail(FLUID_E_INVALID, "fluid_exchange_now moves rows: HALO or GATHER");
     if (nfields < 0 || (nfields > 0 && !fields)) return fail(FLUID_E_INVALID, "bad field list");
+    // the depth is checked against the SHORTEST slab, which every rank knows: a check against this rank's own height
+    // would let the tall ranks of an uneven split into the collective while the short ones return
+    if (kind == FLUID_XCHG_HALO && c->nranks > 1 && (depth < 1 || depth > c->min_slab))
+        return fail(FLUID_E_INVALID, "halo depth %d outside [1, %d] (the shortest slab)", depth, c->min_slab);
     for (int k = 0; k < nfields; ++k) {
         TRY(check_fields(c, {fields[k]}));
         TRY(settle(c, fields[k]));             // the caller is about to look at the rows: no increment may stay pending

@@ -85,8 +85,9 @@ class TorchExchange:
 
     def halo(self, ids, depth):
         lo, hi = self.lo, self.hi
-        if depth < 1 or depth > hi - lo:
-            raise ValueError("halo depth %d does not fit slab of %d rows" % (depth, hi - lo))
+        shortest = self.n // self.nranks                 # the same verdict on every rank (slabs differ by a row when N % P != 0)
+        if depth < 1 or depth > shortest:
+            raise ValueError("halo depth %d does not fit the slabs (shortest: %d rows)" % (depth, shortest))
         ops, landing = [], []
 
         def send(rows, peer):
@@ -186,49 +187,7 @@ class SlabSolver(FluidSolver):
         self.exchange = None
         self.native_exchange = False
         if nranks > 1 and exchange in ("rccl", "auto"):
-            # "auto": the library's own exchange if it comes up on EVERY rank (agreed by an all-reduce, so that no rank
-            # is left on a different transport), else the torch.distributed one
-            import ctypes as C
-            on_dev = dist.get_backend(group) == "nccl"
-            where = self.device if on_dev else "cpu"
-            uid = torch.zeros(capi.RCCL_ID_BYTES, dtype=torch.uint8, device=where)
-            ok = 1
-            if rank == 0:
-                buf = (C.c_ubyte * capi.RCCL_ID_BYTES)()
-                rc = L.fluid_rccl_unique_id(buf, capi.RCCL_ID_BYTES)
-                if rc == capi.OK:
-                    uid.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
-                elif exchange == "rccl":
-                    capi.check(rc)
-                else:
-                    ok = 0
-            src = dist.get_global_rank(group, 0) if group is not None else 0
-            dist.broadcast(uid, src=src, group=group)
-            raw = bytes(uid.cpu().numpy().tobytes())
-            if any(raw):
-                with torch.cuda.device(self.device):
-                    rc = L.fluid_exchange_rccl_attach(self._h, raw, len(raw))
-                if rc != capi.OK:
-                    if exchange == "rccl":
-                        capi.check(rc)
-                    ok = 0
-            else:
-                ok = 0
-            agreed = torch.tensor([ok], dtype=torch.int32, device=where)
-            dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=group)
-            if int(agreed.item()) == 1:
-                # one real exchange before anything depends on it: every rank marks a scratch field with its number,
-                # two halo rows travel each way, and each rank checks whose rows arrived
-                ok = self._native_exchange_selftest()
-                agreed = torch.tensor([ok], dtype=torch.int32, device=where)
-                dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=group)
-                if int(agreed.item()) != 1 and exchange == "rccl":
-                    raise RuntimeError("the library's RCCL exchange delivered the wrong rows in its self-test")
-            if int(agreed.item()) == 1:
-                self.native_exchange = True
-            else:
-                capi.check(L.fluid_exchange_rccl_detach(self._h))
-                exchange = "torch"
+            self._bring_up_native_exchange(L, group, exchange)
         if nranks > 1 and not self.native_exchange:
             if dist.get_backend(group) == "nccl":
                 # batched send/recv must not be the first operation on a NCCL group: start with an all-reduce
@@ -239,6 +198,57 @@ class SlabSolver(FluidSolver):
             off = self.scalar_ptr() - self.arena.data_ptr()
             self.exchange.set_scalar(self.arena[off:off + 4].view(torch.int32))
             self.set_exchange(self.exchange)
+
+    def _bring_up_native_exchange(self, L, group, exchange):
+        """The library's own RCCL exchange, or -- under "auto" -- the agreement of ALL ranks to do without it.
+
+        Every step is followed by an agreement (a MIN all-reduce over torch.distributed) before the next collective
+        step is entered, and nothing raises before the ranks have agreed: a rank that failed alone and left (or raised)
+        would leave its peers waiting inside a collective -- ncclCommInitRank, the id broadcast, the all-reduce itself --
+        until the launcher kills the job.  With "rccl" a failure raises on every rank; with "auto" every rank detaches
+        and takes the torch.distributed exchange."""
+        import ctypes as C
+        on_dev = dist.get_backend(group) == "nccl"
+        where = self.device if on_dev else "cpu"
+
+        def all_ok(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=where)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return int(t.item()) == 1
+
+        def give_up(what):
+            capi.check(L.fluid_exchange_rccl_detach(self._h))
+            if exchange == "rccl":
+                raise RuntimeError("the library's RCCL exchange is not available on every rank: " + what)
+
+        # 1. can every rank load and bind librccl?  (no communication inside; a rank that cannot would return from the
+        #    attach below before ncclCommInitRank, which the others are already blocked in)
+        mine = L.fluid_rccl_available() == capi.OK
+        why = "" if mine else L.fluid_last_error().decode(errors="replace")
+        if not all_ok(mine):
+            return give_up("librccl could not be bound" + (" here: " + why if why else " on another rank"))
+        # 2. the communicator's id from rank 0; a failure travels as an all-zero id, which every rank sees
+        uid = torch.zeros(capi.RCCL_ID_BYTES, dtype=torch.uint8, device=where)
+        if self.rank == 0:
+            buf = (C.c_ubyte * capi.RCCL_ID_BYTES)()
+            if L.fluid_rccl_unique_id(buf, capi.RCCL_ID_BYTES) == capi.OK:
+                uid.copy_(torch.frombuffer(bytearray(buf), dtype=torch.uint8))
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(uid, src=src, group=group)
+        raw = bytes(uid.cpu().numpy().tobytes())
+        if not any(raw):
+            return give_up("rank 0 could not create a communicator id")
+        # 3. the collective attach: every rank enters it (step 1 made sure of that); its result is agreed on afterwards
+        with torch.cuda.device(self.device):
+            rc = L.fluid_exchange_rccl_attach(self._h, raw, len(raw))
+        why = "" if rc == capi.OK else L.fluid_last_error().decode(errors="replace")
+        if not all_ok(rc == capi.OK):
+            return give_up("attach failed" + (" here: " + why if why else " on another rank"))
+        # 4. one real exchange before anything depends on it: every rank marks a scratch field with its number, two halo
+        #    rows travel each way, and each rank checks whose rows arrived
+        if not all_ok(self._native_exchange_selftest() == 1):
+            return give_up("its self-test delivered the wrong rows")
+        self.native_exchange = True
 
     def _native_exchange_selftest(self):
         import ctypes as C

@@ -263,6 +263,10 @@ int fluid_exchange_now(fluid_ctx *ctx, int kind, const int *fields, int nfields,
  * as an in-place ncclAllReduce(max) on the device scalar; everything is enqueued on the context's stream.
  * librccl is bound at run time ($FLUID_RCCL_LIB if set; else an RCCL the process already holds; else the
  * system's), so single-GPU users need none.
+ *   fluid_rccl_available():       FLUID_OK if librccl could be loaded and every entry point bound in THIS process (no
+ *                                 communication): all ranks agree on it (e.g. a MIN all-reduce over the transport that
+ *                                 carries the id) BEFORE anyone enters the collective attach -- a rank that cannot load
+ *                                 the library would otherwise leave its peers waiting inside ncclCommInitRank
  *   fluid_rccl_unique_id():       one rank calls it and hands the FLUID_RCCL_ID_BYTES bytes to all others (any way)
  *   fluid_exchange_rccl_attach(): every rank, with its context (rank / nranks from fluid_create_ex) and that id, on
  *                                 the thread whose current HIP device is the context's: creates the communicator,
@@ -271,6 +275,7 @@ int fluid_exchange_now(fluid_ctx *ctx, int kind, const int *fields, int nfields,
  *   ..._detach():                 removes it (and destroys a communicator the library created)
  *   ..._calls():                  exchanges issued so far: halo, gather, max                                  */
 #define FLUID_RCCL_ID_BYTES 128
+int fluid_rccl_available(void);
 int fluid_rccl_unique_id(void *id, size_t bytes);
 int fluid_exchange_rccl_attach(fluid_ctx *ctx, const void *id, size_t bytes);
 int fluid_exchange_rccl_attach_comm(fluid_ctx *ctx, void *nccl_comm);

@@ -11,6 +11,8 @@ OUT=$R/gpurun_out/prof_$TAG
 ARGS="--grid $GRID --steps 6 --warmup 3 --no-cpu-baseline --no-scaling-base $*"
 case " $* " in *only-ordinary*) ;; *) ARGS="$ARGS --no-ordinary";; esac
 mkdir -p $OUT
+# the hash of the kernel sources this profile is taken from (bench.py checks it against the library it runs with)
+(cd $R && python3 -c "import bench; print(bench.library_source_hash())") > $OUT/source_sha256
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o p --output-format csv -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o p --output-format csv -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1

@@ -19,6 +19,9 @@ import re
 import shutil
 import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import library_source_hash  # noqa: E402  (the hash bench.py compares a summary's against)
+
 
 def short(name):
     return name.replace("void ", "").split("(")[0].replace("fluid::", "")
@@ -77,10 +80,16 @@ def main():
             e["mean_us_under_pmc"] = t / len(dur[k]) / 1e3
         out[k] = e
     if out:
+        # what ties these counters to the kernels they were taken from: bench.py drops them (stale_profile) when the hash of
+        # the library sources it runs with differs.  The profile must be summarised from the same tree it was taken on.
+        stamp = os.path.join(root, "source_sha256")          # written on the GPU box by tools/profile_bench.sh
+        out["_source_sha256"] = open(stamp).read().strip() if os.path.exists(stamp) else library_source_hash()
         path = "profiles/%s_%s%s_pmc.json" % (tag, grid, suffix)
         json.dump(out, open(path, "w"), indent=1)
         print("pmc ->", path)
         for k, v in out.items():
+            if not isinstance(v, dict):
+                continue
             print("  %-30s read(x2) %8.1f MB  write %8.1f MB  valu %s  clock %s" % (
                 k, (v["read_bytes_corrected_x2"] or 0) / 1e6, (v["WRITE_SIZE_bytes"] or 0) / 1e6,
                 "%.3g" % v["valu_insts_per_launch"] if v.get("valu_insts_per_launch") else "-",
