@@ -64,9 +64,9 @@ struct fluid_ctx {
     bool in_halo_exchange = false;
     int tb_nv = 2;                                 // columns per lane of the fused kernel (2: 4 waves/SIMD; 4: 2 waves/SIMD)
     int tb_edge_pct = 40;                          // strip height of the two edge windows, % of the others'
-    int fast_div = 2;                              // 0: always divide; 2 (default): division modes 2 / 4 (each beta proven on the
-                                                   // device first); 1: also the two-term mode 3 where |x0| allows it -- exact as well,
-                                                   // 10-17 % faster on a solve of its own, no faster inside a step
+    int fast_div = 2;                              // FLUID_PARAM_TB_FAST_DIVISION: 0 always divide; 2 (default) division modes 5 / 4;
+                                                   // 3 modes 2 / 4 (round 2's default); 1 also the two-term mode 3 where |x0|
+                                                   // allows it.  Every (mode, beta) is proven on the device first
     // slab decomposition
     int rank = 0, nranks = 1, own0 = 1, own1 = 1, min_slab = 0, halo = 1;
     int reach[FLUID_NFIELDS] = {};            // see "row-slab bookkeeping" below

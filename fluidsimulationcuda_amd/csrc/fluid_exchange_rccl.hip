@@ -45,7 +45,8 @@ static RcclApi* rccl_api()
         if (const char* env = std::getenv("FLUID_RCCL_LIB")) {
             api.handle = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
             if (!api.handle) {
-                api.error = std::string("cannot load $FLUID_RCCL_LIB: ") + (dlerror() ? dlerror() : env);
+                const char* why = dlerror();             // (a second call returns NULL: the message is handed out once)
+                api.error = std::string("cannot load $FLUID_RCCL_LIB: ") + (why ? why : env);
                 return;
             }
         }
@@ -56,7 +57,8 @@ static RcclApi* rccl_api()
         for (const char* nm : fallbacks)
             if (!api.handle) api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
         if (!api.handle) {
-            api.error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+            const char* why = dlerror();
+            api.error = std::string("cannot load librccl: ") + (why ? why : "not found");
             return;
         }
         auto bind = [&](auto& fn, const char* sym) {

@@ -23,9 +23,9 @@ struct TbBatch {
     const void* x[3];
     const void* x0[3];
     void* out[3];
-    float alpha[3], beta[3];     // beta: divisor, or its exact reciprocal in division mode 4
-    double yd[3];                // RN64(1/beta) for division mode 2 (and mode 3's guarded steps)
-    float hi[3], lo[3];          // division mode 3: hi = RD32(1/beta), lo = RN32(1/beta - hi)
+    float alpha[3], beta[3];     // beta: divisor; its exact reciprocal in division mode 4; RN32(1/beta) in mode 5
+    double yd[3];                // RN64(1/beta) for division mode 2 (and the fall-backs of modes 3 and 5)
+    float hi[3], lo[3];          // division mode 3: hi = RD32(1/beta), lo = RN32(1/beta - hi); mode 5: beta * 2^24, -(RN32(1/beta) * 2^-24)
     const unsigned* tiles[3];    // division mode 3: |x0| minima per tile (k_tile_min_abs), tile_pitch words per tile row
     unsigned tile_thr[3];        //   ... and the bit pattern of beta * 2^-72 they must reach
     int tile_pitch;
@@ -52,7 +52,7 @@ struct TileBatch {
     unsigned* tiles[3];
 };
 void launch_tile_min_abs(hipStream_t s, int st, const TileBatch& tb, int count, int pitch, int n, int row_lo, int row_hi, int tile_pitch);
-void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, double yd, float lo, unsigned long long* bad);
+void launch_validate_div(hipStream_t s, int divmode, float beta, float kbeta, double yd, float hi, float lo, unsigned long long* bad);
 void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u, const void* v, int pitch, int n,
                    int row_lo, int row_hi, float dt0, int b);
 void launch_advect2(hipStream_t s, int st, void* da, const void* d0a, int ba, void* db, const void* d0b, int bb, const void* u,

@@ -414,6 +414,22 @@ __global__ __launch_bounds__(256) void k_jacobi_stream(const S* __restrict__ x, 
 //   otherwise, and in the windows and strips on the domain's edge, it divides as mode 2 does.  Velocities
 //   pass unless they have died out; a density with exact zeros outside its support falls back there.
 
+// 5: Markstein's residual correction with the residual kept out of the underflow range by a power of two (round 3).
+//   With r = RN32(1/beta) and S = 2^24:
+//       q0 = D * r;   e = fma(q0, beta*S, D*(-S));   q = fma(e, -(r/S), q0)
+//   -- four PACKED instructions per pair of cells where mode 2 takes six scalar ones.  e = -S*(D - q0*beta) is exact
+//   (q0 is within an ulp of D/beta, so the residual has at most 24 significant bits, and the scale keeps its last bit
+//   at or above 2^-148 even for denormal D: unscaled, it underflows for |D| < 2^-102 and the quotient comes out an ulp
+//   off -- what DESIGN.md section 3 records of the unscaled form), and the last fma rounds q0 + (D - q0*beta)*r once,
+//   which is RN(D/beta) by Markstein's theorem.  The signs are arranged so that -0 / beta = -0.  k_validate_div proves
+//   it per beta for every |D| < 2^104.  Beyond that D*S overflows -- and then e, and q, are inf or NaN, never a finite
+//   wrong number; every later sweep turns anything it computes from a non-finite value into a non-finite value, down
+//   to the rows the wave stores.  So the wave keeps ONE sticky test on what it stores (fma(value, 0, acc): NaN as soon
+//   as a value is inf or NaN), one packed instruction per time step, and a wave that stored anything non-finite runs
+//   its strip again in mode 2 (stores are out of place, so a second pass simply overwrites the first).  Fields that
+//   hold inf or NaN to begin with take that second pass too; nothing else ever does (|D| >= 2^104 ~ 2e31).
+//   Unlike mode 3 this needs no fact about the data: the tiny and denormal ranges a decaying field crosses are exact.
+
 // One lane's share of a row: NV consecutive columns (NV = 2 or 4).
 template <int NV>
 struct Vec {
@@ -483,6 +499,14 @@ __device__ __forceinline__ void buf_stv(half_t*, __amdgpu_buffer_rsrc_t r, unsig
     }
 }
 
+// the per-solve constants of the division (DIVMODE above): what each mode reads
+struct DivK {
+    float beta;           // 0: beta; 4: the exact reciprocal; 5: r = RN32(1/beta); 2, 3: unused
+    double yd;            // 2 (and 3's fallback): RN64(1/beta)
+    float hi, lo;         // 3: hi = RD32(1/beta), lo = RN32(1/beta - hi); 5: hi = beta * 2^24, lo = -(r * 2^-24)
+};
+constexpr float kDiv5NegScale = -0x1p24f;
+
 template <typename S, int NV>
 struct TbArgs {
     const S* xc;          // x   + column offset of this lane
@@ -495,10 +519,8 @@ struct TbArgs {
     unsigned m_lg;        // all ones in the lane whose last component is ghost column 0, else 0
     unsigned m_r[NV];     // all ones in the lane AND component that is ghost column n+1
     int n, q_lo, q_hi, cg;
-    float alpha, beta;
-    double yd;            // DIVMODE 2 (and 3's fallback): 1/beta rounded to double
-    float lo;             // DIVMODE 3: lo = RN32(1/beta - hi); hi travels in `hi`
-    float hi;
+    float alpha;
+    DivK k;               // the division's constants
     S* dc;                // DIVSRC: the divergence field + column offset, its buffer, and -0.5f * h
     __amdgpu_buffer_rsrc_t bd;
     float div_scale;
@@ -520,21 +542,31 @@ __device__ __forceinline__ Vec<NV> fxorv(const Vec<NV>& v, unsigned m)
 // (r + alpha*nb) / beta for one cell (the validator) and for a pair of cells (the kernel; same
 // operations, the compiler emits the packed form of each).
 template <int DIVMODE>
-__device__ __forceinline__ float tb_div(float num, float beta, double yd, float lo = 0.f)
+__device__ __forceinline__ float tb_div(float num, const DivK& k)
 {
-    if (DIVMODE == 0) return num / beta;
-    if (DIVMODE == 4) return num * beta;           // beta holds the exact reciprocal
-    if (DIVMODE == 3) return __builtin_fmaf(num, beta, num * lo);      // beta holds hi
-    return (float)((double)num * yd);
+    if (DIVMODE == 0) return num / k.beta;
+    if (DIVMODE == 4) return num * k.beta;         // beta holds the exact reciprocal
+    if (DIVMODE == 3) return __builtin_fmaf(num, k.hi, num * k.lo);
+    if (DIVMODE == 5) {
+        const float q0 = num * k.beta;
+        const float e = __builtin_fmaf(q0, k.hi, num * kDiv5NegScale);
+        return __builtin_fmaf(e, k.lo, q0);
+    }
+    return (float)((double)num * k.yd);
 }
 template <int DIVMODE>
-__device__ __forceinline__ v2f tb_div2(v2f num, float beta, double yd, float lo = 0.f)
+__device__ __forceinline__ v2f tb_div2(v2f num, const DivK& k)
 {
-    if constexpr (DIVMODE == 4) return num * beta;
+    if constexpr (DIVMODE == 4) return num * k.beta;
     else if constexpr (DIVMODE == 3) {             // v_pk_mul_f32 + v_pk_fma_f32 (four plain v_mul / v_fmac: measured no better)
-        const v2f p = num * lo;
-        return __builtin_elementwise_fma(num, (v2f){beta, beta}, p);
-    } else return (v2f){tb_div<DIVMODE>(num.x, beta, yd), tb_div<DIVMODE>(num.y, beta, yd)};
+        const v2f p = num * k.lo;
+        return __builtin_elementwise_fma(num, (v2f){k.hi, k.hi}, p);
+    } else if constexpr (DIVMODE == 5) {           // 2 x v_pk_mul_f32 + 2 x v_pk_fma_f32
+        const v2f ds = num * kDiv5NegScale;
+        const v2f q0 = num * k.beta;
+        const v2f e = __builtin_elementwise_fma(q0, (v2f){k.hi, k.hi}, ds);
+        return __builtin_elementwise_fma(e, (v2f){k.lo, k.lo}, q0);
+    } else return (v2f){tb_div<DIVMODE>(num.x, k), tb_div<DIVMODE>(num.y, k)};
 }
 
 // One lane's vector of one stage.  Its columns are worked on in pairs (0,1), (2,3), which is how every
@@ -547,7 +579,7 @@ __device__ __forceinline__ v2f tb_div2(v2f num, float beta, double yd, float lo 
 // Operand order and roundings are those of FluidSequential.c:93-94.
 template <int DIVMODE, int NV>
 __device__ __forceinline__ Vec<NV> tb_stencil(const Vec<NV>& up, const Vec<NV>& me, const Vec<NV>& dn, const Vec<NV>& r,
-                                              float alpha, float beta, double yd, float lo = 0.f)
+                                              float alpha, const DivK& k)
 {
     float h[NV];
     h[0] = lane_below0(me.c[NV - 1]) + me.c[1];
@@ -562,7 +594,7 @@ __device__ __forceinline__ Vec<NV> tb_stencil(const Vec<NV>& up, const Vec<NV>& 
         s = s + (v2f){dn.c[p], dn.c[p + 1]};
         if constexpr (DIVMODE != 4) s = s * alpha;       // mode 4: alpha == 1.0f, x * 1.0f is x
         s = (v2f){r.c[p], r.c[p + 1]} + s;
-        s = tb_div2<DIVMODE>(s, beta, yd, lo);
+        s = tb_div2<DIVMODE>(s, k);
         G.c[p] = s.x;
         G.c[p + 1] = s.y;
     }
@@ -574,20 +606,29 @@ __device__ __forceinline__ Vec<NV> tb_stencil(const Vec<NV>& up, const Vec<NV>& 
 // Mode 3 (arg = hi): its fallback, mode 2, must be exact for every a, and the two-term quotient for every a
 // that is zero or at least beta * 2^-98 in magnitude (the dividends the tile test lets through are zero or
 // at least beta * 2^-97, see DIVMODE 3).
+// Mode 5: exact for every a that the quotient of is finite ... or else NOT FINITE (inf / NaN, which the wave's sticky test
+// on its stored rows catches, see DIVMODE 5) -- never a finite value that differs from a / beta.  In practice: exact for
+// |a| < 2^104, non-finite beyond.
 template <int DIVMODE>
-__global__ __launch_bounds__(256) void k_validate_div(float beta, float arg, double yd, float lo, unsigned long long* __restrict__ bad)
+__global__ __launch_bounds__(256) void k_validate_div(float beta, DivK k, unsigned long long* __restrict__ bad)
 {
     unsigned long long n = 0;
     const unsigned long long stride = (unsigned long long)gridDim.x * 256;
     auto differs = [](float got, float ref) { return (ref != ref) ? !(got != got) : (__float_as_uint(got) != __float_as_uint(ref)); };
-    for (unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x; k < (1ull << 32); k += stride) {
-        const float a = __uint_as_float((unsigned)k);
+    DivK k2 = k;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float a = __uint_as_float((unsigned)i);
         const float ref = a / beta;
         if constexpr (DIVMODE == 3) {
             const bool in_range = a == 0.0f || !(__builtin_fabsf(a) < beta * 0x1p-98f);
-            n += differs(tb_div<2>(a, beta, yd), ref) || (in_range && differs(tb_div<3>(a, arg, yd, lo), ref));
+            n += differs(tb_div<2>(a, k2), ref) || (in_range && differs(tb_div<3>(a, k), ref));
+        } else if constexpr (DIVMODE == 5) {
+            const float got = tb_div<5>(a, k);
+            const bool finite = __builtin_fabsf(got) < __builtin_inff();
+            const bool must_be_exact = __builtin_fabsf(a) < 0x1p100f;       // (the claim is 2^104; what matters is: far beyond any field)
+            n += differs(got, ref) && (finite || must_be_exact);
         } else {
-            n += differs(tb_div<DIVMODE>(a, arg, yd), ref);
+            n += differs(tb_div<DIVMODE>(a, k), ref);
         }
     }
     if (n) atomicAdd(bad, n);
@@ -710,6 +751,17 @@ __device__ __forceinline__ void tb_qshift(Vec<NV> (&Q)[N])
     }
 }
 
+// DIVMODE 5's sticky test on a row of the last stage: nf turns NaN -- and stays NaN -- once a value is inf or NaN
+// (x * 0 is +-0 for every finite x).  One packed instruction per pair and time step.
+template <int DIVMODE, int NV>
+__device__ __forceinline__ void tb_sticky(const Vec<NV>& G, v2f& nf)
+{
+    if constexpr (DIVMODE == 5) {
+#pragma unroll
+        for (int p = 0; p < NV; p += 2) nf = __builtin_elementwise_fma((v2f){G.c[p], G.c[p + 1]}, (v2f){0.f, 0.f}, nf);
+    }
+}
+
 // One time step.  Ring s (s = 0..T-1) holds three consecutive rows of "x after
 // s sweeps"; at phase PH its slots are up = PH, me = PH+1, fresh = PH+2 (mod 3).
 // GEN = false: every row any stage touches at this step is interior -- a
@@ -717,7 +769,7 @@ __device__ __forceinline__ void tb_qshift(Vec<NV> (&Q)[N])
 // 0 / n+1): per-stage checks, ghost rows of each stage regenerated from its rows 1 / n.
 template <int T, int DIVMODE, bool EDGE, bool WALL, bool GEN, int PH, typename S, int NV, bool DIVSRC = false>
 __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[T + 1], Vec<NV> (&PX)[3], Vec<NV> (&PQ)[3],
-                                        const TbArgs<S, NV>& a, Vec<NV> (&UR)[3], Vec<NV> (&VR)[3])
+                                        const TbArgs<S, NV>& a, Vec<NV> (&UR)[3], Vec<NV> (&VR)[3], v2f& nf)
 {
     constexpr int UP = PH % 3, ME = (PH + 1) % 3, FR = (PH + 2) % 3;
     // stage 0: row t of x and x0, loaded three steps ago.  The hand-over is an opaque register move on
@@ -765,11 +817,14 @@ __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[
 #pragma unroll
         for (int s = 1; s <= T; ++s) {
             const int q = t - s;                         // row this stage produces now (wave-uniform)
-            Vec<NV> G = tb_stencil<DIVMODE, NV>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, DIVMODE == 3 ? a.hi : a.beta, a.yd, a.lo);
+            Vec<NV> G = tb_stencil<DIVMODE, NV>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.k);
             float v1 = 0.f, vn = 0.f;
             if (EDGE) tb_fix_columns<S, NV>(G, a, v1, vn, WALL && s == T);
             if (s < T) W[s][FR] = G;
-            else tb_store<EDGE, WALL, S, NV>(G, q, (q >= a.q_lo) & (q < a.q_hi), a, v1, vn);
+            else {
+                tb_sticky<DIVMODE, NV>(G, nf);
+                tb_store<EDGE, WALL, S, NV>(G, q, (q >= a.q_lo) & (q < a.q_hi), a, v1, vn);
+            }
         }
     } else {
         // ring writes stay unconditional (selected values), so the rings stay in registers
@@ -777,7 +832,7 @@ __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[
         for (int s = 1; s <= T; ++s) {
             const int q = t - s;
             const bool interior = (q >= 1 && q <= a.n);
-            Vec<NV> G = tb_stencil<DIVMODE, NV>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, DIVMODE == 3 ? a.hi : a.beta, a.yd, a.lo);
+            Vec<NV> G = tb_stencil<DIVMODE, NV>(W[s - 1][UP], W[s - 1][ME], W[s - 1][FR], Q[s], a.alpha, a.k);
             float v1 = 0.f, vn = 0.f;
             if (EDGE) tb_fix_columns<S, NV>(G, a, v1, vn, s == T);
             if (s < T) {
@@ -791,6 +846,7 @@ __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[
                     W[s][ME].c[c] = top_ghost ? flipped_g.c[c] : me.c[c];
                 }
             } else {
+                tb_sticky<DIVMODE, NV>(G, nf);
                 tb_store<EDGE, true, S, NV>(G, q, interior & (q >= a.q_lo) & (q < a.q_hi), a, v1, vn);
             }
         }
@@ -798,10 +854,12 @@ __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[
     tb_qshift<T, T + 1, NV>(Q);
 }
 
+// returns (wave-uniform): did the last stage produce anything that is not finite (DIVMODE 5 only; false otherwise)
 template <int T, int DIVMODE, bool EDGE, bool WALL, typename S, int NV, bool DIVSRC = false>
-__device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs<S, NV>& a)
+__device__ __forceinline__ bool tb_march(int t0, int t1, const TbArgs<S, NV>& a)
 {
     Vec<NV> W[T][3], Q[T + 1], PX[3], PQ[3], UR[3], VR[3];
+    v2f nf = {0.f, 0.f};
     Vec<NV> zero;
 #pragma unroll
     for (int c = 0; c < NV; ++c) zero.c[c] = 0.f;
@@ -833,23 +891,37 @@ __device__ __forceinline__ void tb_march(int t0, int t1, const TbArgs<S, NV>& a)
     int t = t0;
     if constexpr (WALL) {
         for (; t <= t1 && t < T + 1; t += 3) {
-            tb_step<T, DIVMODE, EDGE, WALL, true, 0, S, NV, DIVSRC>(t, W, Q, PX, PQ, a, UR, VR);
-            tb_step<T, DIVMODE, EDGE, WALL, true, 1, S, NV, DIVSRC>(t + 1, W, Q, PX, PQ, a, UR, VR);
-            tb_step<T, DIVMODE, EDGE, WALL, true, 2, S, NV, DIVSRC>(t + 2, W, Q, PX, PQ, a, UR, VR);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 0, S, NV, DIVSRC>(t, W, Q, PX, PQ, a, UR, VR, nf);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 1, S, NV, DIVSRC>(t + 1, W, Q, PX, PQ, a, UR, VR, nf);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 2, S, NV, DIVSRC>(t + 2, W, Q, PX, PQ, a, UR, VR, nf);
         }
     }
     for (; t <= t1 && (!WALL || t + 1 <= a.n); t += 3) {
-        tb_step<T, DIVMODE, EDGE, WALL, false, 0, S, NV, DIVSRC>(t, W, Q, PX, PQ, a, UR, VR);
-        tb_step<T, DIVMODE, EDGE, WALL, false, 1, S, NV, DIVSRC>(t + 1, W, Q, PX, PQ, a, UR, VR);
-        tb_step<T, DIVMODE, EDGE, WALL, false, 2, S, NV, DIVSRC>(t + 2, W, Q, PX, PQ, a, UR, VR);
+        tb_step<T, DIVMODE, EDGE, WALL, false, 0, S, NV, DIVSRC>(t, W, Q, PX, PQ, a, UR, VR, nf);
+        tb_step<T, DIVMODE, EDGE, WALL, false, 1, S, NV, DIVSRC>(t + 1, W, Q, PX, PQ, a, UR, VR, nf);
+        tb_step<T, DIVMODE, EDGE, WALL, false, 2, S, NV, DIVSRC>(t + 2, W, Q, PX, PQ, a, UR, VR, nf);
     }
     if constexpr (WALL) {
         for (; t <= t1; t += 3) {
-            tb_step<T, DIVMODE, EDGE, WALL, true, 0, S, NV, DIVSRC>(t, W, Q, PX, PQ, a, UR, VR);
-            tb_step<T, DIVMODE, EDGE, WALL, true, 1, S, NV, DIVSRC>(t + 1, W, Q, PX, PQ, a, UR, VR);
-            tb_step<T, DIVMODE, EDGE, WALL, true, 2, S, NV, DIVSRC>(t + 2, W, Q, PX, PQ, a, UR, VR);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 0, S, NV, DIVSRC>(t, W, Q, PX, PQ, a, UR, VR, nf);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 1, S, NV, DIVSRC>(t + 1, W, Q, PX, PQ, a, UR, VR, nf);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 2, S, NV, DIVSRC>(t + 2, W, Q, PX, PQ, a, UR, VR, nf);
         }
     }
+    if constexpr (DIVMODE == 5) return __builtin_amdgcn_ballot_w64((nf.x != nf.x) | (nf.y != nf.y)) != 0ull;
+    else return false;
+}
+
+// the four bodies of a march: edge windows replay the ghost columns, wall strips the ghost rows (both wave-uniform)
+template <int T, int DIVMODE, typename S, int NV, bool DIVSRC = false>
+__device__ __forceinline__ bool tb_march_any(bool edge, bool wall, int t0, int t1, const TbArgs<S, NV>& a)
+{
+    if (edge) {
+        if (wall) return tb_march<T, DIVMODE, true, true, S, NV, DIVSRC>(t0, t1, a);
+        return tb_march<T, DIVMODE, true, false, S, NV, DIVSRC>(t0, t1, a);
+    }
+    if (wall) return tb_march<T, DIVMODE, false, true, S, NV, DIVSRC>(t0, t1, a);
+    return tb_march<T, DIVMODE, false, false, S, NV, DIVSRC>(t0, t1, a);
 }
 
 // which (window, strip group) pairs exist (launch_jacobi_tb)
@@ -911,9 +983,9 @@ __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbB
     const bool edge = left_edge || right_edge;
     const int rbw = edge ? rb_edge : rb;
     TbArgs<S, NV> a;
-    a.yd = yd;
-    a.lo = batch.lo[blockIdx.z];
-    a.hi = batch.hi[blockIdx.z];
+    a.k.yd = yd;
+    a.k.lo = batch.lo[blockIdx.z];
+    a.k.hi = batch.hi[blockIdx.z];
     a.x0_inc = batch.x0_inc[blockIdx.z];
     a.q_lo = row_lo + strip * rbw;                       // this wave's output rows [q_lo, q_hi)
     if (a.q_lo >= row_hi) return;                        // wave-uniform
@@ -957,7 +1029,7 @@ __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbB
     a.sx = (b == 1) ? 0x80000000u : 0u;
     a.sy = (b == 2) ? 0x80000000u : 0u;
     a.alpha = alpha;
-    a.beta = beta;
+    a.k.beta = beta;
     const int t0 = max(0, a.q_lo - T), t1 = a.q_hi - 1 + T;
     // a strip whose input rows [q_lo-T, q_hi-1+T] all exist never needs a regenerated ghost row
     const bool wall = (a.q_lo < T) || (a.q_hi - 1 + T > n + 1);      // wave-uniform
@@ -981,19 +1053,17 @@ __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbB
         two_term = tiles != nullptr && __builtin_amdgcn_ballot_w64(low) == 0ull;
     }
     if (two_term) {
-        if (edge) {
-            if (wall) tb_march<T, DIVMODE, true, true, S, NV>(t0, t1, a);
-            else      tb_march<T, DIVMODE, true, false, S, NV>(t0, t1, a);
-        } else {
-            if (wall) tb_march<T, DIVMODE, false, true, S, NV>(t0, t1, a);
-            else      tb_march<T, DIVMODE, false, false, S, NV>(t0, t1, a);
-        }
-    } else if (edge) {
-        if (wall) tb_march<T, DM, true, true, S, NV, DIVSRC>(t0, t1, a);
-        else      tb_march<T, DM, true, false, S, NV, DIVSRC>(t0, t1, a);
+        tb_march_any<T, DIVMODE, S, NV>(edge, wall, t0, t1, a);
     } else {
-        if (wall) tb_march<T, DM, false, true, S, NV, DIVSRC>(t0, t1, a);
-        else      tb_march<T, DM, false, false, S, NV, DIVSRC>(t0, t1, a);
+        const bool again = tb_march_any<T, DM, S, NV, DIVSRC>(edge, wall, t0, t1, a);
+        // mode 5: something this wave stored is inf or NaN -- a dividend beyond 2^104, or a field that holds such values
+        // to begin with.  The strip once more, dividing as mode 2 does; its stores replace the first pass's.
+        if constexpr (DIVMODE == 5) {
+            if (again) {
+                a.k.yd = yd;
+                tb_march_any<T, 2, S, NV>(edge, wall, t0, t1, a);
+            }
+        }
     }
 }
 
@@ -1499,7 +1569,8 @@ void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void
 
 // T in {8,4,2} sweeps per launch, nv in {2,4} columns per lane; batch.count solves per launch.
 // divmode 0: beta; 2: beta unused, yd = RN64(1/beta); 4: beta = exact reciprocal of a power of two and alpha == 1;
-// 3: hi, lo = the two-term reciprocal where the tiles of |x0| minima allow it, yd elsewhere.
+// 3: hi, lo = the two-term reciprocal where the tiles of |x0| minima allow it, yd elsewhere;
+// 5: beta = RN32(1/beta), hi = beta * 2^24, lo = -(RN32(1/beta) * 2^-24), yd for the second pass of a wave that met inf / NaN.
 void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const TbBatch& batch, int pitch, int n, int row_lo,
                       int row_hi, int rb, int rb_edge, bool divsrc)
 {
@@ -1528,6 +1599,7 @@ void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const T
     else FLUID_TB2(TT, DD, 4)
 #define FLUID_TB(TT)                          \
     if (divmode == 4) { FLUID_TB1(TT, 4); }      \
+    else if (divmode == 5) { FLUID_TB1(TT, 5); } \
     else if (divmode == 3) { FLUID_TB1(TT, 3); } \
     else if (divmode == 2) { FLUID_TB1(TT, 2); } \
     else { FLUID_TB1(TT, 0); }
@@ -1540,12 +1612,14 @@ void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const T
     }
     else if (T == 16) {                                  // 2-column lanes only (4-column ones would need > 256 registers)
         if (divmode == 4) { FLUID_TB2(16, 4, 2); }
+        else if (divmode == 5) { FLUID_TB2(16, 5, 2); }
         else if (divmode == 3) { FLUID_TB2(16, 3, 2); }
         else if (divmode == 2) { FLUID_TB2(16, 2, 2); }
         else { FLUID_TB2(16, 0, 2); }
     }
     else if (T == 12) {                                  // 2-column lanes, three waves per SIMD
         if (divmode == 4) { FLUID_TB2(12, 4, 2); }
+        else if (divmode == 5) { FLUID_TB2(12, 5, 2); }
         else if (divmode == 3) { FLUID_TB2(12, 3, 2); }
         else if (divmode == 2) { FLUID_TB2(12, 2, 2); }
         else { FLUID_TB2(12, 0, 2); }
@@ -1570,12 +1644,19 @@ void launch_tile_min_abs(hipStream_t s, int st, const TileBatch& tb, int count, 
     FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_tile_min_abs<S>, grid, dim3(256), 0, s, tb, pitch, n, row_lo, row_hi, tr0, tile_pitch));
 }
 
-// mismatches of division mode `divmode` against a/beta over all 2^32 inputs are added to *bad
-void launch_validate_div(hipStream_t s, int divmode, float beta, float arg, double yd, float lo, unsigned long long* bad)
+// mismatches of division mode `divmode` against a/beta over all 2^32 inputs are added to *bad; kbeta / yd / hi / lo: the
+// constants the mode reads (DivK)
+void launch_validate_div(hipStream_t s, int divmode, float beta, float kbeta, double yd, float hi, float lo, unsigned long long* bad)
 {
-    if (divmode == 4) hipLaunchKernelGGL((k_validate_div<4>), dim3(8192), dim3(256), 0, s, beta, arg, yd, lo, bad);
-    else if (divmode == 3) hipLaunchKernelGGL((k_validate_div<3>), dim3(8192), dim3(256), 0, s, beta, arg, yd, lo, bad);
-    else hipLaunchKernelGGL((k_validate_div<2>), dim3(8192), dim3(256), 0, s, beta, arg, yd, lo, bad);
+    DivK k;
+    k.beta = kbeta;
+    k.yd = yd;
+    k.hi = hi;
+    k.lo = lo;
+    if (divmode == 4) hipLaunchKernelGGL((k_validate_div<4>), dim3(8192), dim3(256), 0, s, beta, k, bad);
+    else if (divmode == 5) hipLaunchKernelGGL((k_validate_div<5>), dim3(8192), dim3(256), 0, s, beta, k, bad);
+    else if (divmode == 3) hipLaunchKernelGGL((k_validate_div<3>), dim3(8192), dim3(256), 0, s, beta, k, bad);
+    else hipLaunchKernelGGL((k_validate_div<2>), dim3(8192), dim3(256), 0, s, beta, k, bad);
 }
 
 void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u, const void* v, int pitch, int n,

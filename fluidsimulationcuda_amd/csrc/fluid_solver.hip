@@ -145,8 +145,9 @@ int timing_collect(fluid_ctx* c)
     } while (0)
 
 // Division mode for `beta` in the temporally blocked kernel (fluid_kernels.hip, DIVMODE): 0 = true division,
-// 4 = multiply by the exact reciprocal (beta a power of two, alpha 1), 3 = guarded two-term reciprocal
-// (hi, lo; two packed instructions per pair of cells), 2 = f64 reciprocal multiply.  Modes 2, 3 and 4 are only
+// 4 = multiply by the exact reciprocal (beta a power of two, alpha 1), 5 = scaled residual correction (four packed
+// instructions per pair of cells, any data), 3 = two-term reciprocal where |x0| allows it (hi, lo; two packed
+// instructions), 2 = f64 reciprocal multiply (six scalar ones).  Modes 2, 3, 4 and 5 are only
 // used after k_validate_div has proven them against a/beta for every one of the 2^32 float inputs on this
 // device -- a few ms, once per (mode, beta) and PROCESS: the proof is about the arithmetic of the device
 // type, so contexts share it (a fresh context used to spend 3 x 2.5 ms re-proving the step's three betas).
@@ -163,7 +164,7 @@ DivProofs& div_proofs()
 struct DivPlan {
     int mode = 0;
     float arg = 0.f;      // what the kernel receives as `beta`: beta (0, 2, 3), 1/beta (4)
-    float hi = 0.f, lo = 0.f;   // mode 3: the two-term reciprocal
+    float hi = 0.f, lo = 0.f;   // mode 3: the two-term reciprocal; mode 5: beta * 2^24 and -(RN32(1/beta) * 2^-24)
     unsigned tile_thr = 0;      // mode 3: bits of beta * 2^-72, what |x0| must reach on a tile (fluid_kernels.hip, DIVMODE 3)
     double yd = 0.0;      // modes 2, 3
 };
@@ -188,9 +189,12 @@ DivPlan division_mode(fluid_ctx* c, float beta, float alpha)
     // mode 4 (pressure solve: alpha 1, beta 4): multiply by the exact reciprocal, and x * 1.0f is x so
     // alpha is not applied at all; else mode 3 when 1/beta splits into two normal floats with lo > 0
     // (not for powers of two: lo = 0 turns inf * lo into NaN); else mode 2, the double-precision reciprocal.
-    // A mode that fails its proof hands over to the next: 3 -> 2 -> 0, 4 -> 2 -> 0.
+    // A mode that fails its proof hands over to the next: 3 -> 2 -> 0, 4 -> 2 -> 0, 5 -> 2 -> 0.
     const bool two_term = c->fast_div == 1 && c->tiles && beta >= 1.0f && beta <= 0x1p24f && std::isnormal(hi) && std::isnormal(lo) && lo > 0.f;
-    int want = (pow2 && alpha == 1.0f) ? 4 : two_term ? 3 : 2;
+    // mode 5 (the default for every other beta): r = RN32(1/beta), beta * 2^24 and r * 2^-24 must be ordinary numbers
+    const bool residual = c->fast_div == 2 && beta >= 0x1p-60f && beta <= 0x1p60f;
+    const float r5_hi = beta * 0x1p24f, r5_lo = -(rbeta * 0x1p-24f);
+    int want = (pow2 && alpha == 1.0f) ? 4 : two_term ? 3 : residual ? 5 : 2;
     unsigned bits;
     std::memcpy(&bits, &beta, sizeof bits);
     int dev = 0;
@@ -207,7 +211,8 @@ DivPlan division_mode(fluid_ctx* c, float beta, float alpha)
             unsigned long long* bad = reinterpret_cast<unsigned long long*>(c->d_scalar) + 1;   // 8-byte slot of the 256-B block
             unsigned long long* hbad = reinterpret_cast<unsigned long long*>(c->h_scalar) + 1;
             if (hipMemsetAsync(bad, 0, sizeof *bad, c->stream) != hipSuccess) return plan;
-            fluid::launch_validate_div(c->stream, want, beta, want == 4 ? rbeta : want == 3 ? hi : beta, plan.yd, lo, bad);
+            fluid::launch_validate_div(c->stream, want, beta, (want == 4 || want == 5) ? rbeta : beta, plan.yd, want == 5 ? r5_hi : hi,
+                                       want == 5 ? r5_lo : lo, bad);
             if (hipMemcpyAsync(hbad, bad, sizeof *bad, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                 hipStreamSynchronize(c->stream) != hipSuccess)
                 return plan;
@@ -218,7 +223,11 @@ DivPlan division_mode(fluid_ctx* c, float beta, float alpha)
         want = want == 2 ? 0 : 2;
     }
     plan.mode = mode;
-    if (mode == 4) plan.arg = rbeta;
+    if (mode == 4 || mode == 5) plan.arg = rbeta;
+    if (mode == 5) {
+        plan.hi = r5_hi;
+        plan.lo = r5_lo;
+    }
     if (mode == 3) {
         plan.hi = hi;
         plan.lo = lo;
@@ -379,13 +388,13 @@ RbTuner& rb_tuner()
 }
 constexpr int kTuneSamples = 2;
 
-unsigned long long tune_key(const fluid_ctx* c, int T, int m, bool mode4, long long rows_n)
+unsigned long long tune_key(const fluid_ctx* c, int T, int m, int divmode, long long rows_n)
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
     unsigned long long h = 1469598103934665603ull;
     for (unsigned long long v : {(unsigned long long)dev, (unsigned long long)c->n, (unsigned long long)rows_n, (unsigned long long)T,
-                                 (unsigned long long)m, (unsigned long long)mode4, (unsigned long long)c->tb_nv, (unsigned long long)c->st,
+                                 (unsigned long long)m, (unsigned long long)divmode, (unsigned long long)c->tb_nv, (unsigned long long)c->st,
                                  (unsigned long long)c->tb_edge_pct}) {
         h ^= v;
         h *= 1099511628211ull;
@@ -732,7 +741,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 int trial = -1;
                 unsigned long long key = 0;
                 if (c->tb_rows <= 0 && c->autotune) {
-                    key = tune_key(c, T, m + (divsrc ? 8 : 0), divmode[first] == 4, hi - lo);
+                    key = tune_key(c, T, m + (divsrc ? 8 : 0), divmode[first], hi - lo);
                     rb = tune_pick(c, key, rb, T, hi - lo, &trial);
                 }
                 // edge windows (ghost columns) cost ~1.6x per row: shorter strips there keep the launch balanced
@@ -1477,7 +1486,7 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
         c->tb_min_cells = value;
         return FLUID_OK;
     case FLUID_PARAM_TB_FAST_DIVISION:
-        if (value < 0 || value > 2) return fail(FLUID_E_INVALID, "TB_FAST_DIVISION must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(FLUID_E_INVALID, "TB_FAST_DIVISION must be 0, 1, 2 or 3");
         c->fast_div = value;
         return FLUID_OK;
     case FLUID_PARAM_TB_AUTOTUNE:

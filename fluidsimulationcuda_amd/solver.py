@@ -151,7 +151,8 @@ class FluidSolver:
         capi.check(capi.lib().fluid_set_jacobi_variant(self._h, variant))
 
     def division_mode(self, alpha, beta):
-        """0 true division, 2 double reciprocal, 3 two-term reciprocal (tile-proved), 4 exact reciprocal."""
+        """0 true division, 2 double reciprocal, 3 two-term reciprocal (tile-proved), 4 exact reciprocal,
+        5 float reciprocal + scaled residual correction."""
         m = C.c_int()
         capi.check(capi.lib().fluid_division_mode(self._h, alpha, beta, C.byref(m)))
         return m.value

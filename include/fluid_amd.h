@@ -58,10 +58,14 @@ enum {
     FLUID_PARAM_TB_FAST_DIVISION = 3 /* how FLUID_JACOBI_TB may replace x/beta by an exactly equivalent reciprocal form,
                                       each after proving the equivalence for that beta on all 2^32 float inputs on
                                       the device.  2 (default): one float multiply when beta is a power of two (and
-                                      alpha 1), else a double-precision multiply.  1: in addition the two-term float
+                                      alpha 1), else Markstein's residual correction with the residual scaled by 2^24
+                                      (two float multiplies and two fused multiply-adds, exact for every |x| < 2^104; a
+                                      wave that stores inf or NaN -- the only thing larger dividends can turn into --
+                                      repeats its strip with the double-precision form).  3: the double-precision
+                                      multiply for every such beta (the round-2 default).  1: the two-term float
                                       reciprocal fma(x, hi, x*lo) in waves whose right-hand side is nowhere smaller
                                       than beta * 2^-72 (which bounds every dividend away from the range where that
-                                      form is one ulp off).  0: always divide                              */
+                                      form is one ulp off), the double-precision form elsewhere.  0: always divide */
     ,FLUID_PARAM_TB_EDGE_ROWS_PCT = 5 /* strip height of the two windows that carry the ghost columns, in % of
                                       the interior windows' (default 40; 0 = same): load balance only  */
     ,FLUID_PARAM_TB_LANE_COLUMNS = 6 /* columns per lane of FLUID_JACOBI_TB: 2 (default; thin waves, 4 per SIMD)
@@ -188,7 +192,8 @@ int fluid_absmax_velocity(fluid_ctx *ctx, int u, int v, float *out);
 int fluid_set_jacobi_variant(fluid_ctx *ctx, int variant);
 /* How FLUID_JACOBI_TB divides by `beta` in a solve with these coefficients (diagnostic; runs the on-device proof
  * if this beta has not been seen): 0 true division, 2 double-precision reciprocal, 3 two-term float reciprocal
- * where the right-hand side allows it (else as 2), 4 exact float reciprocal (beta a power of two, alpha 1). */
+ * where the right-hand side allows it (else as 2), 4 exact float reciprocal (beta a power of two, alpha 1), 5 float
+ * reciprocal with scaled residual correction. */
 int fluid_division_mode(fluid_ctx *ctx, float alpha, float beta, int *mode);
 /* The launch depths FLUID_JACOBI_TB uses for one solve of `iters` sweeps on a grid (or slab) of `rows` x N cells: host
  * logic only (no device needed) -- `pressure_form`: alpha 1 / beta 4; `max_sweeps`, `t16_min_cells` as the parameters of the

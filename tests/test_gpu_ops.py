@@ -211,12 +211,13 @@ TB_SIZES = [1, 2, 3, 4, 5, 7, 8, 9, 14, 61, 64, 95, 96, 97, 111, 112, 113, 119, 
             223, 224, 225, 239, 240, 241, 247, 248, 249, 255, 256, 257, 480, 481, 1022]
 
 
-@pytest.mark.parametrize("lane_cols,max_t,fast_div", [(2, 16, 1), (2, 16, 2), (2, 16, 0), (2, 12, 2), (2, 12, 0), (2, 8, 1), (2, 8, 2), (2, 4, 2), (2, 2, 1),
-                                                      (4, 8, 1), (4, 8, 2), (4, 4, 2), (4, 2, 2)])
+@pytest.mark.parametrize("lane_cols,max_t,fast_div", [(2, 16, 1), (2, 16, 2), (2, 16, 3), (2, 16, 0), (2, 12, 2), (2, 12, 3), (2, 12, 0), (2, 8, 1), (2, 8, 2),
+                                                      (2, 8, 3), (2, 4, 2), (2, 2, 1), (4, 8, 1), (4, 8, 2), (4, 4, 2), (4, 2, 2), (4, 2, 3)])
 @pytest.mark.parametrize("n", TB_SIZES)
 def test_temporal_blocking_matches_oracle(F, oracle, n, lane_cols, max_t, fast_div):
     """Every depth of the fused kernel, both forms (pressure: alpha 1, beta 4; general: the exact
-    reciprocal divisions of fast_div = 1 / 2, or true division with fast_div = 0), on window / strip / wall edge sizes.
+    reciprocal divisions of fast_div = 1 / 2 / 3 -- two-term, scaled residual correction (the default), double-precision
+    reciprocal -- or true division with fast_div = 0), on window / strip / wall edge sizes.
     The launch count is asserted so that a silently shallower schedule fails: 16-sweep launches are
     normally reserved for grids of 8 M cells and more (PARAM_TB_T16_MIN_CELLS forces them here)."""
     from fluidsimulationcuda_amd import capi
@@ -268,11 +269,13 @@ def test_temporal_blocking_power_of_two_beta_paths(F, oracle):
 
 @pytest.mark.parametrize("beta", [3.0, 6.0, 12.0, 10.0, 1.00016, 102.606407, 2682.734, 0.75, 3.3, 5e-5, 7e5])
 def test_temporal_blocking_reciprocal_division_is_exact(F, oracle, beta):
-    """The TB kernel may replace x/beta by (float)((double)x * (1/beta)) once the
-    library has proven the two equal for all 2^32 inputs on the device (or fall
+    """The TB kernel may replace x/beta by an equivalent reciprocal form -- Markstein's residual correction with the
+    residual scaled out of the underflow range (the default), (float)((double)x * (1/beta)), the two-term reciprocal --
+    once the library has proven the two equal for all 2^32 inputs on the device (or fall
     back to dividing).  Either way the bits must match the oracle's true
     division, on ordinary data and on data full of zeros of both signs,
-    denormals and values near overflow."""
+    denormals and values near overflow (3e38 is past the 2^104 the scaled form covers: those waves
+    must notice the inf / NaN they produce and run again with the double form)."""
     from fluidsimulationcuda_amd import capi
     n = 61
     rng = np.random.default_rng(int(beta * 1000) % 2 ** 31)
@@ -280,7 +283,7 @@ def test_temporal_blocking_reciprocal_division_is_exact(F, oracle, beta):
                         dtype=np.float32)
     with F.FluidSolver(n, jacobi=capi.JACOBI_TB) as s:
         s.set_param(capi.PARAM_TB_MIN_CELLS, 0)
-        for fast in (1, 2, 0):       # guarded two-term reciprocal / double reciprocal / true division
+        for fast in (1, 2, 3, 0):    # two-term reciprocal where x0 allows / scaled residual correction / double reciprocal / true division
             s.set_param(capi.PARAM_TB_FAST_DIVISION, fast)
             for kind in ("uniform", "special", "tiny"):
                 if kind == "uniform":
@@ -304,14 +307,18 @@ def test_temporal_blocking_reciprocal_division_is_exact(F, oracle, beta):
                                      "beta=%g fast=%d %s alpha=%g" % (beta, fast, kind, alpha))
 
 
+@pytest.mark.parametrize("fast", [1, 2])
 @pytest.mark.parametrize("max_t", [16, 12, 8, 2])
 @pytest.mark.parametrize("n", [97, 300, 1022])
-def test_two_term_division_only_where_the_right_hand_side_allows_it(F, oracle, n, max_t):
+def test_two_term_division_only_where_the_right_hand_side_allows_it(F, oracle, n, max_t, fast):
     """Division mode 3 (two packed float instructions) is exact for dividends that are zero or at least
     beta * 2^-98; the kernel uses it in a wave only if |x0| >= beta * 2^-72 on every tile the wave touches,
     which bounds every dividend of every sweep from below (fluid_kernels.hip, DIVMODE 3).  Ordinary values
     with islands of exact zeros (both signs), of tiny values (2^-149 .. 2^-60) and of huge ones, in x0 and in
-    the first guess: every cell must still carry the oracle's bits."""
+    the first guess: every cell must still carry the oracle's bits.
+    fast = 2: the same fields through division mode 5 (scaled residual correction), which needs no fact about the data
+    except that a wave whose stored rows hold inf or NaN (the huge islands: 1e37 * beta-sized sums overflow, and past 2^104
+    the scaled residual does) must run again in the double form; islands of inf and NaN themselves are added there."""
     from fluidsimulationcuda_amd import capi
     rng = np.random.default_rng(n + max_t)
     alpha, beta = F.coefficients(n, DT, VISC)
@@ -321,7 +328,7 @@ def test_two_term_division_only_where_the_right_hand_side_allows_it(F, oracle, n
         for _ in range(islands):
             i, j = rng.integers(1, n, 2)
             h, w = rng.integers(1, 40, 2)
-            kind = rng.integers(0, 4)
+            kind = rng.integers(0, 4 if fast == 1 else 6)
             blk = f[i:i + h, j:j + w]
             if kind == 0:
                 blk[...] = np.where(rng.random(blk.shape) < 0.5, 0.0, -0.0)
@@ -329,13 +336,17 @@ def test_two_term_division_only_where_the_right_hand_side_allows_it(F, oracle, n
                 blk[...] = (blk * np.float32(2.0) ** rng.integers(-149, -60, blk.shape)).astype(np.float32)
             elif kind == 2:
                 blk[...] = blk * np.float32(1e-37)
-            else:
+            elif kind == 3:
                 blk[...] = blk * np.float32(1e37)
+            elif kind == 4:
+                blk[...] = blk * np.float32(2.0) ** rng.integers(100, 108, blk.shape)       # around the scaled form's 2^104
+            else:
+                blk[...] = rng.choice(np.array([np.inf, -np.inf, np.nan, 1.0], np.float32), blk.shape)
         return f
 
     with F.FluidSolver(n, params={capi.PARAM_TB_MIN_CELLS: 0, capi.PARAM_TB_T16_MIN_CELLS: 0,
-                                  capi.PARAM_TB_MAX_SWEEPS: max_t, capi.PARAM_TB_FAST_DIVISION: 1}) as s:
-        assert s.division_mode(alpha, beta) == 3 and s.division_mode(1.0, 4.0) == 4
+                                  capi.PARAM_TB_MAX_SWEEPS: max_t, capi.PARAM_TB_FAST_DIVISION: fast}) as s:
+        assert s.division_mode(alpha, beta) == (3 if fast == 1 else 5) and s.division_mode(1.0, 4.0) == 4
         for b, islands in ((0, 6), (1, 0), (2, 2)):
             x, x0 = field(6), field(islands)
             s.upload(u=x, v=x0)
@@ -345,7 +356,7 @@ def test_two_term_division_only_where_the_right_hand_side_allows_it(F, oracle, n
                 oracle.diffuse(b, want, x0, alpha, beta, 16)
             got, nan = s.download("u"), np.isnan(want)       # inf - inf next to the huge islands: any NaN is a NaN
             assert np.array_equal(np.isnan(got), nan)
-            assert_bit_equal(np.where(nan, 0, got), np.where(nan, 0, want), "two-term division n=%d maxT=%d b=%d" % (n, max_t, b))
+            assert_bit_equal(np.where(nan, 0, got), np.where(nan, 0, want), "reciprocal division (fast=%d) n=%d maxT=%d b=%d" % (fast, n, max_t, b))
 
 
 @pytest.mark.parametrize("n", [300, 1022])

@@ -22,7 +22,7 @@ def random_params(rng, capi):
          capi.PARAM_TB_MAX_SWEEPS: int(rng.choice([16, 12, 8, 4, 2])),
          capi.PARAM_TB_LANE_COLUMNS: int(rng.choice([2, 2, 4])),
          capi.PARAM_TB_ROWS: int(rng.choice([0, 0, 1, 2, 5, 17, 64, 1000])),
-         capi.PARAM_TB_FAST_DIVISION: int(rng.choice([0, 1, 2, 2])),
+         capi.PARAM_TB_FAST_DIVISION: int(rng.choice([0, 1, 2, 2, 3])),
          capi.PARAM_FUSE_DIVERGENCE: int(rng.choice([0, 1, 1])),
          capi.PARAM_TB_AUTOTUNE: int(rng.choice([0, 1])),
          capi.PARAM_TB_EDGE_ROWS_PCT: int(rng.choice([40, 0, 100]))}

@@ -112,7 +112,7 @@ def test_step_vs_oracle(F, oracle, n):
             assert_bit_equal(s.download(name), want, "%s n=%d" % (name, n))
 
 
-@pytest.mark.parametrize("fast_div", [2, 1])
+@pytest.mark.parametrize("fast_div", [2, 1, 3])
 @pytest.mark.parametrize("lane_cols,max_t", [(2, 16), (2, 12), (2, 8), (4, 8), (4, 2)])
 @pytest.mark.parametrize("n", [61, 126, 300])
 def test_steps_through_the_fused_kernel_on_signed_zero_fields(F, oracle, n, lane_cols, max_t, fast_div):
@@ -150,7 +150,7 @@ def test_steps_through_the_fused_kernel_on_signed_zero_fields(F, oracle, n, lane
         assert_bit_equal(s.download("v_prev"), v0, "vel_step leaves the divergence in v_prev")
 
 
-@pytest.mark.parametrize("fast_div", [2, 1])
+@pytest.mark.parametrize("fast_div", [2, 1, 3])
 @pytest.mark.parametrize("n", [254, 510])
 def test_decay_through_the_denormal_range_matches_oracle(F, oracle, n, fast_div):
     """With the sources zeroed after step 0 (FluidSequential.c:298-302) every solve restarts from a zero

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """General-form (diffusion) Jacobi solve: us per field-sweep by division mode and launch depth, on ordinary
-(random) data and on all-zero data.  FAST_DIVISION 1 = guarded two-term reciprocal (mode 3), 2 = double
-reciprocal (mode 2), 0 = true division.
+(random) data and on all-zero data.  FAST_DIVISION 2 = scaled residual correction (mode 5, the default), 3 = double
+reciprocal (mode 2), 1 = two-term reciprocal where x0 allows (mode 3), 0 = true division.
     python tools/div_timing.py [grid ...]      (default 4096 8192)"""
 import os
 import sys
@@ -19,13 +19,14 @@ for grid in [int(g) for g in sys.argv[1:]] or [4096, 8192]:
     x0 = rng.random((n + 2, n + 2), dtype=np.float32) - np.float32(0.5)
     alpha, beta = F.coefficients(n, 0.016, 0.0025)
     for data in ("random", "zero"):
-        for max_t in (8, 16):
-            for fast in (1, 2, 0):
+        for max_t in (8, 12, 16):
+            for fast in (2, 3, 1, 0):
                 with F.FluidSolver(n, params={capi.PARAM_TB_FAST_DIVISION: fast, capi.PARAM_TB_MAX_SWEEPS: max_t,
                                               capi.PARAM_TB_T16_MIN_CELLS: 0}) as s:
                     if data == "random":
                         s.upload(u=x, v=x0)
-                    s.diffuse(1, "u", "v", alpha, beta, 16)          # warm-up (+ the division proof)
+                    for _ in range(4):
+                        s.diffuse(1, "u", "v", alpha, beta, 48)      # warm-up: the division proof, the strip-height tuner
                     if data == "random":
                         s.upload(u=x, v=x0)
                     s.timing_enable(True)
