@@ -361,8 +361,34 @@ def main():
         s.close()
         return out + (solve,), fields, calls
 
+    def tune_ordinary(n_):
+        """The sourced step has a launch shape of its own (the first diffusion launch also adds the sources and stores the
+        sums): one launch per step, so its strip heights are measured here, in a throw-away context stepping on
+        re-injected sources, until the tuner has nothing open."""
+        if a.variant != 3 or a.tb_rows or (n_, "ordinary") in tuning:
+            return
+        import torch
+        fields = initialize_parameters(n_, seed=a.seed)
+        s = make(n_)
+        s.load_global(**fields)
+        src = {k: torch.from_numpy(fields[k]).to(s.device) for k in ("u_prev", "v_prev", "dens_prev")}
+        steps = 0
+        for _ in range(48):
+            with torch.cuda.stream(s.torch_stream):
+                for k, t in src.items():
+                    s.interior(k).copy_(t, non_blocking=True)
+            s.step(1, use_sources=True, iters=a.iters)
+            steps += 1
+            if steps % 8 == 0:
+                s.synchronize()
+                if s.autotune_pending() == 0:
+                    break
+        tuning[(n_, "ordinary")] = {"untimed_steps": steps, "shapes_still_open": s.autotune_pending()}
+        s.close()
+
     def run_ordinary(n_, steps, warmup):
         tune(n_)
+        tune_ordinary(n_)
         fields = initialize_parameters(n_, seed=a.seed)
         s = make(n_)
         s.load_global(**fields)

@@ -11,8 +11,8 @@ import numpy as np
 from ._build import LIB
 
 OK, E_INVALID, E_NOMEM, E_HIP, E_COMM = 0, 1, 2, 3, 4
-U, V, DENS, U_PREV, V_PREV, DENS_PREV, TMP0, TMP1, TMP2 = range(9)
-NFIELDS = 9
+U, V, DENS, U_PREV, V_PREV, DENS_PREV, TMP0, TMP1, TMP2, TMP3, TMP4, TMP5 = range(12)
+NFIELDS = 12
 JACOBI_STREAM, JACOBI_LDS, JACOBI_NAIVE, JACOBI_TB = 0, 1, 2, 3
 STORAGE_F32, STORAGE_F16 = 0, 1
 PARAM_TB_MAX_SWEEPS, PARAM_TB_ROWS, PARAM_HALO, PARAM_TB_FAST_DIVISION, PARAM_TB_MIN_CELLS, PARAM_TB_EDGE_ROWS_PCT = 0, 1, 2, 3, 4, 5
@@ -22,9 +22,10 @@ PARAM_TB_AUTOTUNE = 8
 PARAM_FUSE_DIVERGENCE = 9
 PARAM_SLAB_OVERLAP = 10
 PARAM_EARLY_ADVECT = 11
+PARAM_FUSE_ADD_SOURCE = 12
 XCHG_HALO, XCHG_GATHER, XCHG_MAX, XCHG_MAX_BEGIN, XCHG_MAX_END = 0, 1, 2, 3, 4
 RCCL_ID_BYTES = 128
-FIELD_NAMES = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev", "tmp0", "tmp1", "tmp2")
+FIELD_NAMES = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev", "tmp0", "tmp1", "tmp2", "tmp3", "tmp4", "tmp5")
 
 
 class FluidError(RuntimeError):

@@ -73,6 +73,11 @@ struct fluid_ctx {
     bool zero[FLUID_NFIELDS] = {};            // field is all +0 by definition; its memory is NOT (yet) zeroed
     bool pend[FLUID_NFIELDS] = {};            // field owes itself `+ pend_inc[f]` in every cell (deferred add_source of a zero source)
     float pend_inc[FLUID_NFIELDS] = {};
+    // add_source of a real source field, deferred into the first launch of the diffusion that consumes the sum
+    // (fluid_solver.hip: op_add_source / op_diffuse_batch): field f owes itself + src_dt[f] * (field src_of[f] - 1)
+    int src_of[FLUID_NFIELDS] = {};           // 0: nothing owed; else 1 + the id of the source field
+    float src_dt[FLUID_NFIELDS] = {};
+    bool fuse_add_source = true;              // FLUID_PARAM_FUSE_ADD_SOURCE
     fluid_exchange_fn xchg = nullptr;
     void* xchg_user = nullptr;
     fluid_detail::RcclExchange* rccl = nullptr;   // the library's own exchange, when attached (fluid_exchange_rccl_attach)

@@ -30,7 +30,8 @@ struct TbBatch {
     unsigned tile_thr[3];        //   ... and the bit pattern of beta * 2^-72 they must reach
     int tile_pitch;
     void* div[3];                // divergence-sourced launch (launch_jacobi_tb divsrc): x / x0 hold u / v, the divergence is
-    float div_scale;             //   written here; div_scale = -0.5f * h
+    float div_scale;             //   written here; div_scale = -0.5f * h.  Source-adding launch (addsrc): x is the source
+                                 //   field s, x0 + div_scale * s (div_scale = dt) is the right-hand side and is written here
     int b[3];
     int x_zero[3];               // first guess known to be all +0: never read
     float x0_inc[3];             // added to every x0 value as it is loaded (-0.0f: nothing pending)
@@ -42,7 +43,9 @@ void launch_add_source(hipStream_t s, int st, void* x, const void* src, int pitc
 void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void* x0, void* out, int pitch, int n,
                    int row_lo, int row_hi, float alpha, float beta, int b);
 void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const TbBatch& batch, int pitch, int n, int row_lo,
-                      int row_hi, int rb, int rb_edge, bool divsrc = false);
+                      int row_hi, int rb, int rb_edge, bool divsrc = false, bool addsrc = false);
+// the launches that exist with addsrc: 2-column lanes, 8 / 12 / 16 sweeps, division modes 0, 2 and 5
+inline bool jacobi_tb_addsrc_exists(int T, int divmode, int nv) { return nv == 2 && (T == 8 || T == 12 || T == 16) && (divmode == 0 || divmode == 2 || divmode == 5); }
 // tiles of kTileRows x kTileCols interior cells, tile (r, c) = rows 1 + r*kTileRows.., columns 1 + c*kTileCols..
 constexpr int kTileRows = 32, kTileCols = 64;
 inline int tile_rows(int n) { return (n + kTileRows - 1) / kTileRows; }

@@ -522,8 +522,9 @@ struct TbArgs {
     float alpha;
     DivK k;               // the division's constants
     S* dc;                // DIVSRC: the divergence field + column offset, its buffer, and -0.5f * h
-    __amdgpu_buffer_rsrc_t bd;
+    __amdgpu_buffer_rsrc_t bd;   // (ADDSRC: the field that receives x0 + dt * source, and dt in div_scale)
     float div_scale;
+    int s_lo, s_hi;       // ADDSRC: rows of it this wave stores (its strip, plus the wall row next to it)
     unsigned sx, sy;      // sign masks: flip across vertical / horizontal walls
     float x0_inc;         // pending add_source increment of the right-hand side (-0.0f: none)
     bool st_rg_lane, is_lg;
@@ -767,7 +768,7 @@ __device__ __forceinline__ void tb_sticky(const Vec<NV>& G, v2f& nf)
 // GEN = false: every row any stage touches at this step is interior -- a
 // branch-free body.  GEN = true (the few steps of a wall strip that sit on rows
 // 0 / n+1): per-stage checks, ghost rows of each stage regenerated from its rows 1 / n.
-template <int T, int DIVMODE, bool EDGE, bool WALL, bool GEN, int PH, typename S, int NV, bool DIVSRC = false>
+template <int T, int DIVMODE, bool EDGE, bool WALL, bool GEN, int PH, typename S, int NV, bool DIVSRC = false, bool ADDSRC = false>
 __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[T + 1], Vec<NV> (&PX)[3], Vec<NV> (&PQ)[3],
                                         const TbArgs<S, NV>& a, Vec<NV> (&UR)[3], Vec<NV> (&VR)[3], v2f& nf)
 {
@@ -784,11 +785,27 @@ __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[
     } else {
         W[0][FR] = take<NV>(PX[PH]);
         Q[0] = take<NV>(PQ[PH]);
+        if constexpr (ADDSRC) {
+            // add_source inside the solve's first launch (FluidSequential.c:78-82 with the SWAP of :181 / :201 / :209 behind
+            // it): the first guess x IS the source field s and the right-hand side is x0 + dt * s -- formed here row by row,
+            // in the reference's order (the product rounded, then the sum), handed to the stages and stored OUT OF PLACE for
+            // the solve's later launches (neighbouring waves still read the raw rows of x0, so it cannot go back in place;
+            // the solver swaps the two buffers afterwards).  Ghost cells included, as add_source touches every cell.
 #pragma unroll
-        for (int p = 0; p < NV; p += 2) {                // x0 + dt*0 where an add_source was deferred, else x0 + (-0) = x0
-            const v2f q = (v2f){Q[0].c[p], Q[0].c[p + 1]} + a.x0_inc;
-            Q[0].c[p] = q.x;
-            Q[0].c[p + 1] = q.y;
+            for (int p = 0; p < NV; p += 2) {
+                const v2f ds = (v2f){W[0][FR].c[p], W[0][FR].c[p + 1]} * a.div_scale;
+                const v2f q = (v2f){Q[0].c[p], Q[0].c[p + 1]} + ds;
+                Q[0].c[p] = as_stored<S>(q.x);           // fp16 storage: what a separate add_source pass would hand on
+                Q[0].c[p + 1] = as_stored<S>(q.y);
+            }
+            buf_stv<NV>(a.dc, a.bd, (((t >= a.s_lo) & (t < a.s_hi)) ? a.st_off : kBufOff) + (unsigned)t * a.row_bytes, Q[0]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < NV; p += 2) {            // x0 + dt*0 where an add_source was deferred, else x0 + (-0) = x0
+                const v2f q = (v2f){Q[0].c[p], Q[0].c[p + 1]} + a.x0_inc;
+                Q[0].c[p] = q.x;
+                Q[0].c[p + 1] = q.y;
+            }
         }
     }
     {   // refill the slot with row t+3: three steps of arithmetic cover the memory latency.  Rows past
@@ -855,7 +872,7 @@ __device__ __forceinline__ void tb_step(int t, Vec<NV> (&W)[T][3], Vec<NV> (&Q)[
 }
 
 // returns (wave-uniform): did the last stage produce anything that is not finite (DIVMODE 5 only; false otherwise)
-template <int T, int DIVMODE, bool EDGE, bool WALL, typename S, int NV, bool DIVSRC = false>
+template <int T, int DIVMODE, bool EDGE, bool WALL, typename S, int NV, bool DIVSRC = false, bool ADDSRC = false>
 __device__ __forceinline__ bool tb_march(int t0, int t1, const TbArgs<S, NV>& a)
 {
     Vec<NV> W[T][3], Q[T + 1], PX[3], PQ[3], UR[3], VR[3];
@@ -879,7 +896,7 @@ __device__ __forceinline__ bool tb_march(int t0, int t1, const TbArgs<S, NV>& a)
         // for a row at the top of the loop counts 7 younger operations on both paths into it instead
         // of draining the queue
         buf_stv<NV>(a.oc, a.bo, kBufOff, zero);
-        if constexpr (DIVSRC) buf_stv<NV>(a.dc, a.bd, kBufOff, zero);      // (a step of this variant stores a second row)
+        if constexpr (DIVSRC || ADDSRC) buf_stv<NV>(a.dc, a.bd, kBufOff, zero);      // (a step of these variants stores a second row)
         __builtin_amdgcn_sched_barrier(0);               // in this order
     }
     // whole triples only: up to two surplus steps load nothing (rows past the field) and store nothing
@@ -891,21 +908,21 @@ __device__ __forceinline__ bool tb_march(int t0, int t1, const TbArgs<S, NV>& a)
     int t = t0;
     if constexpr (WALL) {
         for (; t <= t1 && t < T + 1; t += 3) {
-            tb_step<T, DIVMODE, EDGE, WALL, true, 0, S, NV, DIVSRC>(t, W, Q, PX, PQ, a, UR, VR, nf);
-            tb_step<T, DIVMODE, EDGE, WALL, true, 1, S, NV, DIVSRC>(t + 1, W, Q, PX, PQ, a, UR, VR, nf);
-            tb_step<T, DIVMODE, EDGE, WALL, true, 2, S, NV, DIVSRC>(t + 2, W, Q, PX, PQ, a, UR, VR, nf);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 0, S, NV, DIVSRC, ADDSRC>(t, W, Q, PX, PQ, a, UR, VR, nf);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 1, S, NV, DIVSRC, ADDSRC>(t + 1, W, Q, PX, PQ, a, UR, VR, nf);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 2, S, NV, DIVSRC, ADDSRC>(t + 2, W, Q, PX, PQ, a, UR, VR, nf);
         }
     }
     for (; t <= t1 && (!WALL || t + 1 <= a.n); t += 3) {
-        tb_step<T, DIVMODE, EDGE, WALL, false, 0, S, NV, DIVSRC>(t, W, Q, PX, PQ, a, UR, VR, nf);
-        tb_step<T, DIVMODE, EDGE, WALL, false, 1, S, NV, DIVSRC>(t + 1, W, Q, PX, PQ, a, UR, VR, nf);
-        tb_step<T, DIVMODE, EDGE, WALL, false, 2, S, NV, DIVSRC>(t + 2, W, Q, PX, PQ, a, UR, VR, nf);
+        tb_step<T, DIVMODE, EDGE, WALL, false, 0, S, NV, DIVSRC, ADDSRC>(t, W, Q, PX, PQ, a, UR, VR, nf);
+        tb_step<T, DIVMODE, EDGE, WALL, false, 1, S, NV, DIVSRC, ADDSRC>(t + 1, W, Q, PX, PQ, a, UR, VR, nf);
+        tb_step<T, DIVMODE, EDGE, WALL, false, 2, S, NV, DIVSRC, ADDSRC>(t + 2, W, Q, PX, PQ, a, UR, VR, nf);
     }
     if constexpr (WALL) {
         for (; t <= t1; t += 3) {
-            tb_step<T, DIVMODE, EDGE, WALL, true, 0, S, NV, DIVSRC>(t, W, Q, PX, PQ, a, UR, VR, nf);
-            tb_step<T, DIVMODE, EDGE, WALL, true, 1, S, NV, DIVSRC>(t + 1, W, Q, PX, PQ, a, UR, VR, nf);
-            tb_step<T, DIVMODE, EDGE, WALL, true, 2, S, NV, DIVSRC>(t + 2, W, Q, PX, PQ, a, UR, VR, nf);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 0, S, NV, DIVSRC, ADDSRC>(t, W, Q, PX, PQ, a, UR, VR, nf);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 1, S, NV, DIVSRC, ADDSRC>(t + 1, W, Q, PX, PQ, a, UR, VR, nf);
+            tb_step<T, DIVMODE, EDGE, WALL, true, 2, S, NV, DIVSRC, ADDSRC>(t + 2, W, Q, PX, PQ, a, UR, VR, nf);
         }
     }
     if constexpr (DIVMODE == 5) return __builtin_amdgcn_ballot_w64((nf.x != nf.x) | (nf.y != nf.y)) != 0ull;
@@ -913,15 +930,15 @@ __device__ __forceinline__ bool tb_march(int t0, int t1, const TbArgs<S, NV>& a)
 }
 
 // the four bodies of a march: edge windows replay the ghost columns, wall strips the ghost rows (both wave-uniform)
-template <int T, int DIVMODE, typename S, int NV, bool DIVSRC = false>
+template <int T, int DIVMODE, typename S, int NV, bool DIVSRC = false, bool ADDSRC = false>
 __device__ __forceinline__ bool tb_march_any(bool edge, bool wall, int t0, int t1, const TbArgs<S, NV>& a)
 {
     if (edge) {
-        if (wall) return tb_march<T, DIVMODE, true, true, S, NV, DIVSRC>(t0, t1, a);
-        return tb_march<T, DIVMODE, true, false, S, NV, DIVSRC>(t0, t1, a);
+        if (wall) return tb_march<T, DIVMODE, true, true, S, NV, DIVSRC, ADDSRC>(t0, t1, a);
+        return tb_march<T, DIVMODE, true, false, S, NV, DIVSRC, ADDSRC>(t0, t1, a);
     }
-    if (wall) return tb_march<T, DIVMODE, false, true, S, NV, DIVSRC>(t0, t1, a);
-    return tb_march<T, DIVMODE, false, false, S, NV, DIVSRC>(t0, t1, a);
+    if (wall) return tb_march<T, DIVMODE, false, true, S, NV, DIVSRC, ADDSRC>(t0, t1, a);
+    return tb_march<T, DIVMODE, false, false, S, NV, DIVSRC, ADDSRC>(t0, t1, a);
 }
 
 // which (window, strip group) pairs exist (launch_jacobi_tb)
@@ -935,11 +952,12 @@ constexpr int tb_waves_per_simd(int T, int NV) { return NV == 2 ? (T <= 8 ? 4 : 
 
 // blockIdx.z picks one of up to three independent solves of the same shape (u, v and density
 // diffusion): more waves per launch, hence taller strips and less pipeline-fill redundancy.
-template <int T, int DIVMODE, int NV, typename S, bool DIVSRC = false>
+template <int T, int DIVMODE, int NV, typename S, bool DIVSRC = false, bool ADDSRC = false>
 __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbBatch batch, int pitch, int n, int row_lo,
                                                                              int row_hi, int rb, int rb_edge, TbGrid g)
 {
     static_assert(!DIVSRC || DIVMODE == 4, "the divergence-sourced launch is the first launch of a pressure solve");
+    static_assert(!(DIVSRC && ADDSRC) && (!ADDSRC || DIVMODE != 3), "one second store per launch; mode 3's tiles are taken from the summed field");
     // Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  The
     // grid is one-dimensional, a multiple of 8 long, and renumbered so that XCD k works through the
     // k-th contiguous eighth of the (window, strip group) list, windows fastest: the blocks an XCD
@@ -990,6 +1008,8 @@ __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbB
     a.q_lo = row_lo + strip * rbw;                       // this wave's output rows [q_lo, q_hi)
     if (a.q_lo >= row_hi) return;                        // wave-uniform
     a.q_hi = min(a.q_lo + rbw, row_hi);
+    a.s_lo = a.q_lo == 1 ? 0 : a.q_lo;                   // (ADDSRC) the strips next to a wall store the wall row too
+    a.s_hi = a.q_hi == n + 1 ? n + 2 : a.q_hi;
     const int k = win * VS - HL + lane;                  // vector index: columns 1+NV*k .. NV+NV*k
     const int nvec = (n + NV - 1) / NV;
     const bool ld_ok = k <= pitch / NV - C0 - 1;         // the whole vector lies inside the row (k >= -HL >= -C0 always)
@@ -1005,7 +1025,7 @@ __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbB
         a.bx = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(x), 0, (batch.x_zero[blockIdx.z] && !DIVSRC) ? 0u : field_bytes, 0x00020000);
         a.br = __builtin_amdgcn_make_buffer_rsrc(const_cast<S*>(x0), 0, field_bytes, 0x00020000);
         a.bo = __builtin_amdgcn_make_buffer_rsrc(out, 0, field_bytes, 0x00020000);
-        S* dv = DIVSRC ? static_cast<S*>(batch.div[blockIdx.z]) : out;
+        S* dv = (DIVSRC || ADDSRC) ? static_cast<S*>(batch.div[blockIdx.z]) : out;
         a.dc = dv + cofs;
         a.bd = __builtin_amdgcn_make_buffer_rsrc(dv, 0, field_bytes, 0x00020000);
         a.div_scale = batch.div_scale;
@@ -1055,14 +1075,11 @@ __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbB
     if (two_term) {
         tb_march_any<T, DIVMODE, S, NV>(edge, wall, t0, t1, a);
     } else {
-        const bool again = tb_march_any<T, DM, S, NV, DIVSRC>(edge, wall, t0, t1, a);
+        const bool again = tb_march_any<T, DM, S, NV, DIVSRC, ADDSRC>(edge, wall, t0, t1, a);
         // mode 5: something this wave stored is inf or NaN -- a dividend beyond 2^104, or a field that holds such values
         // to begin with.  The strip once more, dividing as mode 2 does; its stores replace the first pass's.
         if constexpr (DIVMODE == 5) {
-            if (again) {
-                a.k.yd = yd;
-                tb_march_any<T, 2, S, NV>(edge, wall, t0, t1, a);
-            }
+            if (again) tb_march_any<T, 2, S, NV, false, ADDSRC>(edge, wall, t0, t1, a);
         }
     }
 }
@@ -1572,7 +1589,7 @@ void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void
 // 3: hi, lo = the two-term reciprocal where the tiles of |x0| minima allow it, yd elsewhere;
 // 5: beta = RN32(1/beta), hi = beta * 2^24, lo = -(RN32(1/beta) * 2^-24), yd for the second pass of a wave that met inf / NaN.
 void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const TbBatch& batch, int pitch, int n, int row_lo,
-                      int row_hi, int rb, int rb_edge, bool divsrc)
+                      int row_hi, int rb, int rb_edge, bool divsrc, bool addsrc)
 {
     const int rows = row_hi - row_lo;
     if (rows <= 0 || batch.count <= 0) return;
@@ -1605,7 +1622,18 @@ void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const T
     else { FLUID_TB1(TT, 0); }
 #define FLUID_TBD(TT) \
     FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_jacobi_tb<TT, 4, 2, S, true>), grid, block, 0, s, batch, pitch, n, row_lo, row_hi, rb, rb_edge, g))
-    if (divsrc) {                                        // first launch of a pressure solve, right-hand side computed from (u, v)
+#define FLUID_TBA2(TT, DD) \
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_jacobi_tb<TT, DD, 2, S, false, true>), grid, block, 0, s, batch, pitch, n, row_lo, row_hi, rb, rb_edge, g))
+#define FLUID_TBA(TT)                       \
+    if (divmode == 5) { FLUID_TBA2(TT, 5); }      \
+    else if (divmode == 2) { FLUID_TBA2(TT, 2); } \
+    else { FLUID_TBA2(TT, 0); }
+    if (addsrc) {                                        // first launch of a diffusion: right-hand side = x0 + dt * x, stored out of place
+        if (T == 16) { FLUID_TBA(16) }
+        else if (T == 12) { FLUID_TBA(12) }
+        else { FLUID_TBA(8) }
+    }
+    else if (divsrc) {                                   // first launch of a pressure solve, right-hand side computed from (u, v)
         if (T == 16) { FLUID_TBD(16); }
         else if (T == 12) { FLUID_TBD(12); }
         else { FLUID_TBD(8); }
@@ -1627,6 +1655,8 @@ void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const T
     else if (T == 8) { FLUID_TB(8) }
     else if (T == 4) { FLUID_TB(4) }
     else { FLUID_TB(2) }
+#undef FLUID_TBA
+#undef FLUID_TBA2
 #undef FLUID_TBD
 #undef FLUID_TB
 #undef FLUID_TB1

@@ -251,6 +251,7 @@ void wrote(fluid_ctx* c, int f, int reach)
 {
     c->reach[f] = c->nranks > 1 ? reach : kEverywhere;
     c->pend[f] = false;                        // overwritten: whatever the old contents still owed is moot
+    c->src_of[f] = 0;
 }
 
 int need_list(fluid_ctx* c, const std::vector<int>& fields, int reach)
@@ -298,6 +299,19 @@ void rows(const fluid_ctx* c, int reach, int* lo, int* hi)
 // reader settles it with the real kernel first (here), and a writer that replaces the field drops it.
 int settle(fluid_ctx* c, int f)
 {
+    if (c->src_of[f]) {
+        // an add_source of a real source field that no diffusion launch took over (see op_add_source): the kernel of its own
+        const int s = c->src_of[f] - 1;
+        const int reach = c->nranks > 1 ? std::min({c->reach[f], c->reach[s], exchange_cap(c)}) : 0;
+        int lo, hi;
+        rows(c, reach, &lo, &hi);
+        if (lo == 1) lo = 0;
+        if (hi == c->n + 1) hi = c->n + 2;
+        c->src_of[f] = 0;
+        TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->st, c->f[f], c->f[s], c->pitch, lo, hi, c->src_dt[f]));
+        wrote(c, f, reach);
+        return FLUID_OK;
+    }
     if (!c->pend[f]) return FLUID_OK;
     const int reach = c->nranks > 1 ? std::min(c->reach[f], exchange_cap(c)) : 0;
     int lo, hi;
@@ -334,11 +348,16 @@ void mark_zero(fluid_ctx* c, int f)
 {
     c->zero[f] = true;
     c->pend[f] = false;
+    c->src_of[f] = 0;
     c->reach[f] = kEverywhere;
 }
 
 // ---- operators -------------------------------------------------------------------
-int op_add_source(fluid_ctx* c, int x, int s, float dt)
+// `defer` (only the step functions pass it: nothing can touch x or s between this call and the diffusion that follows it
+// there): with the fused Jacobi kernel a real source is not added now -- the first launch of the solve whose right-hand
+// side x is and whose first guess s is (FluidSequential.c:181, :201, :209: SWAP, then diffuse) reads both fields anyway,
+// forms x + dt*s as it loads them and stores the sum out of place (op_diffuse_batch).  Any other reader settles it first.
+int op_add_source(fluid_ctx* c, int x, int s, float dt, bool defer = false)
 {
     // pointwise: valid as far out as both operands are
     const int reach = c->nranks > 1 ? std::min({c->reach[x], c->reach[s], exchange_cap(c)}) : 0;
@@ -357,6 +376,12 @@ int op_add_source(fluid_ctx* c, int x, int s, float dt)
         }
         TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->st, c->f[x], nullptr, c->pitch, lo, hi, inc));
     } else {
+        TRY(settle(c, s));                 // (a source that is itself owed something: never inside a step)
+        if (defer && c->fuse_add_source && c->variant == fluid::JACOBI_TB && c->tb_nv == 2) {
+            c->src_of[x] = 1 + s;
+            c->src_dt[x] = dt;
+            return FLUID_OK;               // reach[x] unchanged: nothing was written
+        }
         TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->st, c->f[x], c->f[s], c->pitch, lo, hi, dt));
     }
     wrote(c, x, reach);
@@ -580,8 +605,10 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                      int scratch_base = 0)
 {
     static const int kScratchAll[3] = {FLUID_TMP0, FLUID_TMP1, FLUID_TMP2};
+    static const int kSumAll[3] = {FLUID_TMP3, FLUID_TMP4, FLUID_TMP5};      // x0 + dt*s of a deferred add_source lands here
     if (scratch_base < 0 || scratch_base + count > 3) return fail(FLUID_E_INVALID, "a batch holds 1 to 3 solves");
     const int* kScratch = kScratchAll + scratch_base;      // (a solve that runs beside another batch on a second stream takes the last one)
+    const int* kSum = kSumAll + scratch_base;
     if (iters < 0 || (iters & 1)) return fail(FLUID_E_INVALID, "sweep count must be even and >= 0 (got %d)", iters);
     if (count < 1 || count > 3) return fail(FLUID_E_INVALID, "a batch holds 1 to 3 solves");
     for (int k = 0; k < count; ++k) {
@@ -591,8 +618,17 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
             if (sv[j].x == sv[k].x || sv[j].x == sv[k].x0 || sv[j].x0 == sv[k].x)
                 return fail(FLUID_E_INVALID, "diffuse: the solves of a batch must not share fields");
     }
-    if (iters == 0) return FLUID_OK;
+    if (iters == 0) {
+        for (int k = 0; k < count; ++k) TRY(settle(c, sv[k].x0));           // (no launch to take a deferred source over)
+        return FLUID_OK;
+    }
     for (int k = 0; k < count; ++k) TRY(materialize_zero(c, sv[k].x0));     // a pending increment rides along (TbBatch::x0_inc)
+    // a deferred add_source (op_add_source) rides in the first launch if that is a fused one of a shape that exists with the
+    // second store, the source is this solve's first guess and all solves of the launch agree; else it is settled now
+    bool add_src = c->src_of[sv[0].x0] != 0;
+    for (int k = 0; k < count; ++k)
+        add_src = add_src && c->src_of[sv[k].x0] == 1 + sv[k].x && c->src_dt[sv[k].x0] == c->src_dt[sv[0].x0] && !c->zero[sv[k].x] &&
+                  !c->pend[sv[k].x] && !c->src_of[sv[k].x] && ds == nullptr;
     hipEvent_t stop;
     TRY(timing_begin(c, FLUID_TIME_DIFFUSION, &stop));
     const bool multi = c->nranks > 1;
@@ -607,6 +643,17 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         divmode[k] = plan[k].mode;
         same_mode = same_mode && divmode[k] == divmode[0];
         all_mode4 = all_mode4 && divmode[k] == 4;
+    }
+    {
+        const bool canonical0 = c->st == fluid::STORAGE_F16;
+        const long long cells0 = (long long)(c->nranks > 1 ? c->min_slab : c->n) * c->n;
+        const bool small0 = (canonical0 ? (long long)c->n * c->n : cells0 * count) < c->tb_min_cells;
+        // the depth of the first launch: what the loop below will pick when nothing is short (a short reach there exchanges
+        // first, or shortens the launch -- in which case the source is settled there, before that launch)
+        const int T0 = pick_sweeps(c, iters, iters, canonical0, small0, cells0, all_mode4);
+        add_src = add_src && same_mode && fluid::jacobi_tb_addsrc_exists(T0, divmode[0], c->tb_nv);
+        if (!add_src)
+            for (int k = 0; k < count; ++k) TRY(settle(c, sv[k].x0));
     }
     // division mode 3 needs |x0| >= beta * 2^-72 wherever it is used: minima of |x0| per tile, once per solve (x0 does not
     // change during it), over the rows of x0 that are valid here; tiles beyond them read 0 = "divide the long way"
@@ -664,6 +711,10 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
             r = reach_now();
         }
         const int T = canonical ? wantT : pick(std::min(r, remaining));
+        if (add_src && k == 0 && !fluid::jacobi_tb_addsrc_exists(T, divmode[0], c->tb_nv)) {
+            add_src = false;                   // a shallower first launch than planned (short reach): the kernel of its own after all
+            for (int j = 0; j < count; ++j) TRY(settle(c, sv[j].x0));
+        }
         int lo, hi;
         rows(c, multi ? std::min(r - T, exchange_cap(c)) : 0, &lo, &hi);
         if (T == 1) {
@@ -702,6 +753,14 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 bt.count = m;
                 bt.tile_pitch = fluid::tile_pitch(c->n);
                 const bool divsrc = ds != nullptr && k == 0;
+                const bool addsrc = add_src && k == 0;
+                if (addsrc) {
+                    for (int j = first, q = 0; j < last; ++j, ++q) {
+                        bt.div[q] = c->f[kSum[j]];
+                        bt.x0_inc[q] = -0.0f;
+                    }
+                    bt.div_scale = c->src_dt[sv[first].x0];
+                }
                 if (divsrc) {
                     bt.x[0] = c->f[ds->u];
                     bt.x0[0] = c->f[ds->v];
@@ -741,13 +800,13 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 int trial = -1;
                 unsigned long long key = 0;
                 if (c->tb_rows <= 0 && c->autotune) {
-                    key = tune_key(c, T, m + (divsrc ? 8 : 0), divmode[first], hi - lo);
+                    key = tune_key(c, T, m + (divsrc ? 8 : 0) + (addsrc ? 16 : 0), divmode[first], hi - lo);
                     rb = tune_pick(c, key, rb, T, hi - lo, &trial);
                 }
                 // edge windows (ghost columns) cost ~1.6x per row: shorter strips there keep the launch balanced
                 const int rb_edge = std::min(rb, edge_rows(rb));
                 if (trial >= 0) TRY(tune_begin(c, key, trial));
-                fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], c->tb_nv, bt, c->pitch, c->n, lo, hi, rb, rb_edge, divsrc);
+                fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], c->tb_nv, bt, c->pitch, c->n, lo, hi, rb, rb_edge, divsrc, addsrc);
                 if (trial >= 0) TRY(tune_end(c));
                 if (c->timing) {
                     c->launches += 1;
@@ -758,6 +817,18 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         }
         r = multi ? std::min(r - T, exchange_cap(c)) : kEverywhere;
         if (ds && k == 0 && multi) c->reach[sv[0].x0] = std::max(0, std::min(c->reach[sv[0].x0], r));   // the divergence exists where this launch stored it
+        if (add_src && k == 0) {
+            // the sums were stored out of place, on the rows this launch computed (+ the wall rows next to them): the
+            // right-hand side takes that buffer, the scratch field the old one
+            for (int j = 0; j < count; ++j) {
+                const int x0 = sv[j].x0;
+                std::swap(c->f[x0], c->f[kSum[j]]);
+                c->zero[kSum[j]] = false;
+                wrote(c, kSum[j], 0);
+                wrote(c, x0, std::max(0, r));
+            }
+            add_src = false;
+        }
         for (int j = 0; j < count; ++j) {
             c->zero[cur[j]] = false;       // from now on this buffer is just the other half of the ping-pong
             c->zero[nxt[j]] = false;
@@ -1033,8 +1104,8 @@ int vel_step(fluid_ctx* c, float dt, float visc, int iters)
 {
     const int U = FLUID_U, V = FLUID_V, U0 = FLUID_U_PREV, V0 = FLUID_V_PREV;
     float alpha, beta;
-    TRY(op_add_source(c, U, U0, dt));
-    TRY(op_add_source(c, V, V0, dt));
+    TRY(op_add_source(c, U, U0, dt, /*defer=*/true));
+    TRY(op_add_source(c, V, V0, dt, /*defer=*/true));
     coefficients(c->n, dt, visc, &alpha, &beta);
     // one exchange feeds both solves: right-hand sides iters-1 rows out, first guesses iters rows
     const int h = std::min(iters, c->halo);
@@ -1053,7 +1124,7 @@ int dens_step(fluid_ctx* c, float dt, float diff, int iters)
 {
     const int X = FLUID_DENS, X0 = FLUID_DENS_PREV;
     float alpha, beta;
-    TRY(op_add_source(c, X, X0, dt));
+    TRY(op_add_source(c, X, X0, dt, /*defer=*/true));
     coefficients(c->n, dt, diff, &alpha, &beta);
     TRY(op_diffuse(c, 0, X0, X, alpha, beta, iters));
     TRY(vmax_begin(c, FLUID_U, FLUID_V));
@@ -1068,9 +1139,9 @@ int dens_step(fluid_ctx* c, float dt, float diff, int iters)
 int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
 {
     const int U = FLUID_U, V = FLUID_V, D = FLUID_DENS, U0 = FLUID_U_PREV, V0 = FLUID_V_PREV, D0 = FLUID_DENS_PREV;
-    TRY(op_add_source(c, U, U0, dt));
-    TRY(op_add_source(c, V, V0, dt));
-    TRY(op_add_source(c, D, D0, dt));
+    TRY(op_add_source(c, U, U0, dt, /*defer=*/true));
+    TRY(op_add_source(c, V, V0, dt, /*defer=*/true));
+    TRY(op_add_source(c, D, D0, dt, /*defer=*/true));
     // right-hand sides and first guesses together (zeroed sources are valid everywhere and skipped)
     TRY(need(c, {U, V, D, U0, V0, D0}, std::min(iters, c->halo)));
     float av, bv, ad, bd;
@@ -1500,6 +1571,9 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
         return FLUID_OK;
     case FLUID_PARAM_EARLY_ADVECT:
         c->early_advect = value != 0;
+        return FLUID_OK;
+    case FLUID_PARAM_FUSE_ADD_SOURCE:
+        c->fuse_add_source = value != 0;
         return FLUID_OK;
     case FLUID_PARAM_TB_T16_MIN_CELLS:
         if (value < -1) return fail(FLUID_E_INVALID, "TB_T16_MIN_CELLS must be >= 0, or -1 for the default rule");

@@ -36,12 +36,15 @@ extern "C" {
 #define FLUID_E_COMM    4 /* the multi-GPU exchange callback failed or is missing */
 
 /* Field ids of a context = the six arrays of the reference's main()
- * (FluidSequential.c:277-282) plus three library-owned scratch fields. */
+ * (FluidSequential.c:277-282) plus six library-owned scratch fields: TMP0-2 are the other half of a solve's
+ * ping-pong (the reference malloc()s one per diffuse call, :88), TMP3-5 receive `x + dt*s` when add_source runs
+ * inside the first launch of the solve that consumes it (FLUID_PARAM_FUSE_ADD_SOURCE). */
 enum {
     FLUID_U = 0, FLUID_V = 1, FLUID_DENS = 2,
     FLUID_U_PREV = 3, FLUID_V_PREV = 4, FLUID_DENS_PREV = 5,
     FLUID_TMP0 = 6, FLUID_TMP1 = 7, FLUID_TMP2 = 8,
-    FLUID_NFIELDS = 9
+    FLUID_TMP3 = 9, FLUID_TMP4 = 10, FLUID_TMP5 = 11,
+    FLUID_NFIELDS = 12
 };
 
 /* Jacobi kernels (identical results, different data paths).  TB = temporally
@@ -86,6 +89,10 @@ enum {
     ,FLUID_PARAM_FUSE_DIVERGENCE = 9 /* 1 (default): inside fluid_step / fluid_vel_step on one GPU the divergence of a
                                       projection is computed by the first launch of the pressure solve that consumes it
                                       (no separate pass over u, v); 0: its own kernel first.  Speed only.        */
+    ,FLUID_PARAM_FUSE_ADD_SOURCE = 12 /* 1 (default): inside fluid_step / fluid_vel_step / fluid_dens_step a non-zero source is
+                                      added by the first launch of the diffusion that consumes the sum (which reads both
+                                      operands anyway: the source is its first guess) and stored out of place, instead of
+                                      by a pass of its own over the field; 0: add_source as its own kernel.  Speed only. */
     ,FLUID_PARAM_TB_MIN_CELLS = 4  /* FLUID_JACOBI_TB fuses sweeps only on slabs of at least this many cells
                                       (default 0: always); smaller ones run one-thread-per-cell sweeps   */
 };

@@ -130,8 +130,20 @@ def test_steps_through_the_fused_kernel_on_signed_zero_fields(F, oracle, n, lane
     per_solve = len(tb_schedule(40, max_t, deep=lane_cols == 2))
     with F.FluidSolver(n, params=params) as s:
         s.upload(u=u, v=v, dens=dens, u_prev=u0, v_prev=v0, dens_prev=dens0)
+        s.timing_enable(True)
+        s.timing_read(reset=True)
         s.step(1, use_sources=True)
+        t = s.timing_read(reset=True)
+        s.timing_enable(False)
+        # the sourced step: add_source (FluidSequential.c:78-82) runs inside the first launch of the batched diffusion --
+        # no k_add_source launch at all -- wherever that launch exists with the second store (2-column lanes, 8+ sweeps,
+        # not the tile-guarded division); else three passes of their own.  The same launches and sweeps either way.
+        fused = lane_cols == 2 and fast_div != 1
+        assert t["source_calls"] == (0 if fused else 3), t
+        assert t["jacobi_launches"] == 3 * per_solve and t["sweeps"] == 200, t
         oracle.step_src(u, v, dens, u0, v0, dens0)
+        for name, want in (("u", u), ("v", v), ("dens", dens), ("u_prev", u0), ("v_prev", v0), ("dens_prev", dens0)):
+            assert_bit_equal(s.download(name), want, "%s n=%d cols=%d maxT=%d sourced step" % (name, n, lane_cols, max_t))
         for z in range(2):
             s.timing_enable(True)
             s.timing_read(reset=True)
@@ -148,6 +160,56 @@ def test_steps_through_the_fused_kernel_on_signed_zero_fields(F, oracle, n, lane
         oracle.vel_step(u, v, u0, v0)
         assert_bit_equal(s.download("u"), u, "vel_step u")
         assert_bit_equal(s.download("v_prev"), v0, "vel_step leaves the divergence in v_prev")
+
+
+@pytest.mark.parametrize("storage", [0, 1])
+@pytest.mark.parametrize("n", [97, 510, 1022])
+def test_add_source_inside_the_first_diffusion_launch(F, oracle, n, storage):
+    """FLUID_PARAM_FUSE_ADD_SOURCE: x + dt*s formed by the first launch of the diffusion (first guess = s, right-hand side
+    = the sum; FluidSequential.c:78-82, :181, :201, :209) and stored out of place, against the same steps with k_add_source as a
+    pass of its own -- all six fields bit for bit, three sourced steps in a row (the sum lands in a scratch buffer that
+    trades places with the field, so the second and third step run on swapped buffers), fp32 and fp16 storage, and for
+    fp32 against the oracle; then through fluid_vel_step / fluid_dens_step, and a sourced step whose first launch is a
+    shallow one (6 sweeps per solve: no second store exists for it, so the source is settled by its own kernel)."""
+    from fluidsimulationcuda_amd import capi
+    rng = np.random.default_rng(n + storage)
+    f0 = {k: rnd(rng, n) for k in ("u", "v", "dens")}
+    srcs = [{k: rnd(rng, n) for k in ("u_prev", "v_prev", "dens_prev")} for _ in range(3)]
+    names = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev")
+    got = {}
+    for fuse in (1, 0):
+        with F.FluidSolver(n, storage=storage, params={capi.PARAM_TB_MIN_CELLS: 0, capi.PARAM_TB_T16_MIN_CELLS: 0,
+                                                       capi.PARAM_FUSE_ADD_SOURCE: fuse}) as s:
+            s.upload(**f0)
+            s.timing_enable(True)
+            out = []
+            for src in srcs:
+                s.upload(**src)
+                s.timing_read(reset=True)
+                s.step(1, use_sources=True)
+                t = s.timing_read(reset=True)
+                assert t["source_calls"] == (0 if fuse else 3), t
+                out.append({k: s.download(k) for k in names})
+            s.upload(**srcs[0])
+            s.vel_step()
+            s.dens_step()
+            out.append({k: s.download(k) for k in names})
+            s.upload(**srcs[1])
+            s.timing_read(reset=True)
+            s.step(1, use_sources=True, iters=6)
+            assert s.timing_read(reset=True)["source_calls"] == 3
+            out.append({k: s.download(k) for k in names})
+            got[fuse] = out
+    for z, (a, b) in enumerate(zip(got[1], got[0])):
+        for k in names:
+            assert_bit_equal(a[k], b[k], "%s after call %d, n=%d storage=%d: fused add_source vs its own kernel" % (k, z, n, storage))
+    if storage == 0:
+        u, v, dens = (f0[k].copy() for k in ("u", "v", "dens"))
+        for z, src in enumerate(srcs):
+            u0, v0, d0 = (src[k].copy() for k in ("u_prev", "v_prev", "dens_prev"))
+            oracle.step_src(u, v, dens, u0, v0, d0)
+            for k, want in zip(names, (u, v, dens, u0, v0, d0)):
+                assert_bit_equal(got[1][z][k], want, "%s after sourced step %d vs the oracle, n=%d" % (k, z, n))
 
 
 @pytest.mark.parametrize("fast_div", [2, 1, 3])
