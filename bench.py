@@ -335,6 +335,7 @@ def main():
         if a.variant != 3 or a.tb_rows or (n_, world) in tuning:
             return
         s = make(n_)
+        s.set_param(12, 0)      # FUSE_ADD_SOURCE off here: the sourced step's own launch shape is tune_ordinary()'s business
         s.load_global(**initialize_parameters(n_, seed=a.seed))
         s.step(1, use_sources=True, iters=a.iters)
         steps = 1

@@ -297,7 +297,26 @@ void rows(const fluid_ctx* c, int reach, int* lo, int* hi)
 // write of the whole field.  With the fused Jacobi kernel the increment stays PENDING instead: the
 // solve that consumes the field as its right-hand side adds it to each row as it loads it, any other
 // reader settles it with the real kernel first (here), and a writer that replaces the field drops it.
+int settle_source(fluid_ctx* c, int f);
+
 int settle(fluid_ctx* c, int f)
+{
+    if (c->src_of[f]) return settle_source(c, f);
+    if (!c->pend[f]) return FLUID_OK;
+    const int reach = c->nranks > 1 ? std::min(c->reach[f], exchange_cap(c)) : 0;
+    int lo, hi;
+    rows(c, reach, &lo, &hi);
+    if (lo == 1) lo = 0;
+    if (hi == c->n + 1) hi = c->n + 2;
+    const float inc = c->pend_inc[f];
+    c->pend[f] = false;
+    TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->st, c->f[f], nullptr, c->pitch, lo, hi, inc));
+    return FLUID_OK;
+}
+
+// the deferred add_source of a real source field only (a pending constant increment stays pending: the fused kernel
+// applies it on load)
+int settle_source(fluid_ctx* c, int f)
 {
     if (c->src_of[f]) {
         // an add_source of a real source field that no diffusion launch took over (see op_add_source): the kernel of its own
@@ -310,17 +329,7 @@ int settle(fluid_ctx* c, int f)
         c->src_of[f] = 0;
         TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->st, c->f[f], c->f[s], c->pitch, lo, hi, c->src_dt[f]));
         wrote(c, f, reach);
-        return FLUID_OK;
     }
-    if (!c->pend[f]) return FLUID_OK;
-    const int reach = c->nranks > 1 ? std::min(c->reach[f], exchange_cap(c)) : 0;
-    int lo, hi;
-    rows(c, reach, &lo, &hi);
-    if (lo == 1) lo = 0;
-    if (hi == c->n + 1) hi = c->n + 2;
-    const float inc = c->pend_inc[f];
-    c->pend[f] = false;
-    TIMED(c, FLUID_TIME_SOURCE, fluid::launch_add_source(c->stream, c->st, c->f[f], nullptr, c->pitch, lo, hi, inc));
     return FLUID_OK;
 }
 
@@ -619,7 +628,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 return fail(FLUID_E_INVALID, "diffuse: the solves of a batch must not share fields");
     }
     if (iters == 0) {
-        for (int k = 0; k < count; ++k) TRY(settle(c, sv[k].x0));           // (no launch to take a deferred source over)
+        for (int k = 0; k < count; ++k) TRY(settle_source(c, sv[k].x0));    // (no launch to take a deferred source over)
         return FLUID_OK;
     }
     for (int k = 0; k < count; ++k) TRY(materialize_zero(c, sv[k].x0));     // a pending increment rides along (TbBatch::x0_inc)
@@ -653,7 +662,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         const int T0 = pick_sweeps(c, iters, iters, canonical0, small0, cells0, all_mode4);
         add_src = add_src && same_mode && fluid::jacobi_tb_addsrc_exists(T0, divmode[0], c->tb_nv);
         if (!add_src)
-            for (int k = 0; k < count; ++k) TRY(settle(c, sv[k].x0));
+            for (int k = 0; k < count; ++k) TRY(settle_source(c, sv[k].x0));
     }
     // division mode 3 needs |x0| >= beta * 2^-72 wherever it is used: minima of |x0| per tile, once per solve (x0 does not
     // change during it), over the rows of x0 that are valid here; tiles beyond them read 0 = "divide the long way"
@@ -713,7 +722,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         const int T = canonical ? wantT : pick(std::min(r, remaining));
         if (add_src && k == 0 && !fluid::jacobi_tb_addsrc_exists(T, divmode[0], c->tb_nv)) {
             add_src = false;                   // a shallower first launch than planned (short reach): the kernel of its own after all
-            for (int j = 0; j < count; ++j) TRY(settle(c, sv[j].x0));
+            for (int j = 0; j < count; ++j) TRY(settle_source(c, sv[j].x0));
         }
         int lo, hi;
         rows(c, multi ? std::min(r - T, exchange_cap(c)) : 0, &lo, &hi);

@@ -183,14 +183,21 @@ def checksums():
         json.dump(rows, f, indent=1)
 
 
-def trajectory_checksums():
+TRAJECTORIES = ((1022, 10), (4094, 5), (8190, 3), (16382, 2))
+
+
+def trajectory_checksums(only=None):
     """The reference's own loop over several steps (FluidSequential.c:289-324: sources at step 0 only, zeroed before every
     later step) at the grids where arrays are too big to commit: CRC-32 of u, v and dens after EVERY step, so that the
-    decay of the fields towards zero is pinned to the reference itself, not only its first step."""
+    decay of the fields towards zero is pinned to the reference itself, not only its first step.  `only` = (n, steps):
+    that grid alone, merged into the file (16382^2 takes minutes per step on one core)."""
     import json
     import zlib
     rows = []
-    for n, steps in ((1022, 10), (4094, 5), (8190, 3)):
+    path = os.path.join(OUT, "trajectory_checksums.json")
+    if only is not None:
+        rows = [r for r in json.load(open(path)) if r["n"] != only[0]]
+    for n, steps in ((only,) if only is not None else TRAJECTORIES):
         r = Reference(n, 40)
         dens, dens0, u, u0, v, v0 = r.initialize(seed=1)
         for z in range(1, steps + 1):
@@ -201,7 +208,8 @@ def trajectory_checksums():
             rows.append(dict(n=n, step=z, crc_u=zlib.crc32(u.view(np.uint8).reshape(-1)), crc_v=zlib.crc32(v.view(np.uint8).reshape(-1)),
                              crc_dens=zlib.crc32(dens.view(np.uint8).reshape(-1)), max_u=float(np.abs(u).max())))
             print(rows[-1])
-    with open(os.path.join(OUT, "trajectory_checksums.json"), "w") as f:
+    rows.sort(key=lambda r: (r["n"], r["step"]))
+    with open(path, "w") as f:
         json.dump(rows, f, indent=1)
 
 
@@ -209,8 +217,8 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["checksums"]:
         checksums()
         sys.exit(0)
-    if sys.argv[1:] == ["trajectory"]:
-        trajectory_checksums()
+    if sys.argv[1:2] == ["trajectory"]:
+        trajectory_checksums(tuple(int(v) for v in sys.argv[2:4]) if len(sys.argv) >= 4 else None)
         sys.exit(0)
     if sys.argv[1:] == ["state_grid"]:
         state_grid()

@@ -116,6 +116,62 @@ def test_reference_crc_at_full_size(F, n):
     assert (crc(gu), crc(gv), crc(gd)) == (row["crc_u"], row["crc_v"], row["crc_dens"])
 
 
+def test_fp16_storage_against_fp32_at_16384(F):
+    """BASELINE config 5 at its own size: the reference's loop (FluidSequential.c:289-312; its own initializeParameters,
+    glibc rand seed 1) for one sourced and two plain steps at N = 16382 with fp16 fields, against the fp32 fields of the same
+    steps on the GPU -- which test_reference_crc_at_full_size / test_reference_trajectory_crc tie to the compiled
+    reference's bytes (the reference allocates float, :277-282: it has no fp16 mode, so the distance from the fp32 result is
+    this mode's only tie to it).  Asserted: every field stays within 2^-8 of the fp32 field's largest magnitude (fp16
+    carries 11 bits; ~40 roundings per step accumulate a few ulps).  Reported (gpurun_out/f16_vs_f32_16384.json, quoted in
+    DESIGN.md): the largest relative error over the cells that carry at least 2^-6 of the field's magnitude, and the step
+    of the decaying loop at which the fp16 velocities have flushed to exact zeros (fp16's smallest subnormal is 6e-8;
+    the reference's fields shrink by orders of magnitude per step)."""
+    from oracle.oracle import Oracle
+    from fluidsimulationcuda_amd import capi
+    n = 16382
+    BOUND = {"u": 2.0 ** -3, "v": 2.0 ** -3, "dens": 2.0 ** -6}
+    dens, dens0, u, u0, v, v0 = Oracle().initialize_glibc(n, seed=1)
+    report = {"n": n, "asserted_bound_of_scale": BOUND, "steps": []}
+    with F.FluidSolver(n) as s32, F.FluidSolver(n, storage=capi.STORAGE_F16) as s16:
+        for s in (s32, s16):
+            s.upload(u=u, v=v, dens=dens, u_prev=u0, v_prev=v0, dens_prev=dens0)
+        del dens0, u0, v0
+        a32, a16 = np.empty_like(u), np.empty_like(u)
+        for z in (1, 2, 3):
+            for s in (s32, s16):
+                s.step(1, use_sources=(z == 1))
+            row = {"step": z}
+            for k in ("u", "v", "dens"):
+                s32.download(k, out=a32)
+                s16.download(k, out=a16)
+                scale = float(np.abs(a32).max())
+                np.subtract(a16, a32, out=a16)
+                np.abs(a16, out=a16)
+                err = float(a16.max())
+                big = np.abs(a32) >= scale * 2.0 ** -6
+                rel = float((a16[big] / np.abs(a32[big])).max()) if big.any() else 0.0
+                row[k] = {"max_abs_fp32": scale, "max_abs_err": err, "err_over_scale": err / scale if scale else 0.0,
+                          "max_rel_err_cells_above_scale_2^-6": rel}
+                assert np.isfinite(err) and err <= scale * BOUND[k], "step %d %s: err %.3g vs scale %.3g" % (z, k, err, scale)
+            report["steps"].append(row)
+        # how long until the fp16 velocities are exact zeros (fp32 keeps shrinking through its denormals much longer)
+        flushed = None
+        for z in range(4, 41):
+            s16.step(1)
+            if s16.absmax_velocity("u", "v") == 0.0:
+                flushed = z
+                break
+        report["fp16_velocities_exactly_zero_after_step"] = flushed
+        s32.step(max((flushed or 40) - 3, 0))
+        report["fp32_max_velocity_at_that_step"] = s32.absmax_velocity("u", "v")
+    assert flushed is not None, "the decaying loop must flush fp16 velocities to zero within 40 steps"
+    out = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "f16_vs_f32_16384.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    print("fp16 vs fp32 at 16384^2:", json.dumps(report))
+
+
 def test_fp16_fused_launches_at_16384_match_rounded_oracle(F, oracle):
     """BASELINE config 4's grid (fp16 fields, fp32 accumulate): two fused launches of 8 sweeps of the
     density-diffusion form at N = 16382 against the oracle's fp32 sweeps with one numpy.float16 rounding
@@ -256,13 +312,14 @@ def test_two_steps_at_16384_fp16_on_eight_slabs_match_one_context(F):
         assert_bit_equal(got[k], one[k], "%s: 8 slabs vs one context at 16384^2, fp16 storage" % k)
 
 
-@pytest.mark.parametrize("n", [1022, 4094, 8190])
+@pytest.mark.parametrize("n", [1022, 4094, 8190, 16382])
 def test_reference_trajectory_crc(F, n):
-    """The reference's own loop over 10 (N = 1022) / 5 (N = 4094) / 3 (N = 8190) steps -- sources at step 0 only, fields decaying by one
+    """The reference's own loop over 10 (N = 1022) / 5 (N = 4094) / 3 (N = 8190) / 2 (N = 16382) steps -- sources at step 0 only, fields decaying by one
     to two orders of magnitude per step -- as the compiled reference ran it (tests/golden/trajectory_checksums.json,
     make_golden.py trajectory): CRC-32 of u, v and dens after every single step, device-resident throughout."""
     from oracle.oracle import Oracle
     rows = [r for r in json.load(open(os.path.join(GOLDEN, "trajectory_checksums.json"))) if r["n"] == n]
+    assert len(rows) >= 2
     dens, dens0, u, u0, v, v0 = Oracle().initialize_glibc(n, seed=1)
     with F.FluidSolver(n) as s:
         s.upload(u=u, v=v, dens=dens, u_prev=u0, v_prev=v0, dens_prev=dens0)

@@ -152,6 +152,7 @@ def test_steps_through_the_fused_kernel_on_signed_zero_fields(F, oracle, n, lane
             s.timing_enable(False)
             # the three diffusions share their launches; each projection's solve has its own
             assert t["jacobi_launches"] == 3 * per_solve and t["sweeps"] == 200, t
+            assert t["source_calls"] == 0, "the add_source of a zeroed source stays pending on the field: no kernel"
             oracle.step(u, v, dens, u0, v0, dens0)
             for name, want in (("u", u), ("v", v), ("dens", dens), ("u_prev", u0), ("v_prev", v0), ("dens_prev", dens0)):
                 assert_bit_equal(s.download(name), want, "%s n=%d cols=%d maxT=%d step %d" % (name, n, lane_cols, max_t, z + 2))
