@@ -23,6 +23,7 @@ PARAM_FUSE_DIVERGENCE = 9
 PARAM_SLAB_OVERLAP = 10
 PARAM_EARLY_ADVECT = 11
 PARAM_FUSE_ADD_SOURCE = 12
+PARAM_XCHG_OVERLAP = 13
 XCHG_HALO, XCHG_GATHER, XCHG_MAX, XCHG_MAX_BEGIN, XCHG_MAX_END = 0, 1, 2, 3, 4
 RCCL_ID_BYTES = 128
 FIELD_NAMES = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev", "tmp0", "tmp1", "tmp2", "tmp3", "tmp4", "tmp5")
@@ -100,6 +101,8 @@ SIGNATURES = {
     "fluid_op_diffuse_tol": [_ctx, _i, _i, _i, _f, _f, _f, _i, _i, C.POINTER(_i), C.POINTER(_f)],
     "fluid_set_exchange": [_ctx, EXCHANGE_FN, C.c_void_p],
     "fluid_exchange_now": [_ctx, _i, C.POINTER(_i), _i, _i],
+    "fluid_exchange_stream": [_ctx, C.POINTER(C.c_void_p)],
+    "fluid_split_launches": [_ctx, C.POINTER(C.c_longlong)],
     "fluid_rccl_available": [],
     "fluid_rccl_unique_id": [C.c_void_p, C.c_size_t],
     "fluid_exchange_rccl_attach": [_ctx, C.c_void_p, C.c_size_t],

@@ -41,6 +41,16 @@ struct fluid_ctx {
     hipStream_t stream2 = nullptr;        // slabs: the density diffusion runs beside the velocity path (full_step)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool slab_overlap = true;
+    // slabs: every exchange is enqueued on a stream of its own (one stream per communicator: the ranks issue their
+    // collectives in one order), ordered against the compute stream(s) by events.  An exchange issued `async` is not waited
+    // for at once: the first launch of the solve it feeds runs its interior strips -- rows that depend on this slab's own rows
+    // only -- while the halo rows travel, and its edge strips behind the exchange's event (fluid_solver.hip: call_exchange,
+    // op_diffuse_batch).  FLUID_PARAM_XCHG_OVERLAP.
+    hipStream_t xstream = nullptr;
+    hipEvent_t ev_xbegin = nullptr, ev_xdone = nullptr;
+    bool xchg_overlap = true;
+    bool xpend = false;                    // an async exchange is in flight: whoever consumes its rows waits on ev_xdone first
+    long long split_launches = 0;          // first launches that ran as interior + edge strips around an exchange
     bool early_advect = true;                      // FLUID_PARAM_EARLY_ADVECT
     float vmax_prev[2] = {-1.0f, -1.0f};           // the last global bounds of the velocity / density advection (-1: none yet)
     void* f[FLUID_NFIELDS] = {};

@@ -64,6 +64,40 @@ int check_fields(const fluid_ctx* c, std::initializer_list<int> ids)
     return FLUID_OK;
 }
 
+// Every exchange goes through here.  With a comm stream (slabs) the callback runs with that stream as "the context's
+// stream": behind everything enqueued on the compute stream so far (event), and the compute stream behind it again (event)
+// -- at once, or, for an exchange issued `async`, when xchg_join() is called by whoever consumes the rows.  A callback that
+// enqueues elsewhere or waits on the host (the tests' in-process fabric, a torch.distributed exchange on its own stream) is
+// merely not overlapped.
+int call_exchange(fluid_ctx* c, int kind, const int* ids, int count, int depth, float* scalar, bool async = false)
+{
+    if (!c->xstream || !c->xchg_overlap) return c->xchg(c->xchg_user, kind, ids, count, depth, scalar);
+    if (c->xpend) {                                      // one exchange in flight at a time: the earlier one is joined first
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_xdone, 0));
+        c->xpend = false;
+    }
+    HIP_TRY(hipEventRecord(c->ev_xbegin, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->xstream, c->ev_xbegin, 0));
+    hipStream_t compute = c->stream;
+    c->stream = c->xstream;
+    const int rc = c->xchg(c->xchg_user, kind, ids, count, depth, scalar);
+    c->stream = compute;
+    if (rc != 0) return rc;
+    HIP_TRY(hipEventRecord(c->ev_xdone, c->xstream));
+    if (async) c->xpend = true;
+    else HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_xdone, 0));
+    return 0;
+}
+
+// the current compute stream waits for the exchange in flight (if any); `keep`: another stream still has to join it too
+int xchg_join(fluid_ctx* c, bool keep = false)
+{
+    if (!c->xpend) return FLUID_OK;
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_xdone, 0));
+    if (!keep) c->xpend = false;
+    return FLUID_OK;
+}
+
 int exchange(fluid_ctx* c, int kind, std::initializer_list<int> fields, int depth, float* scalar = nullptr)
 {
     if (c->nranks == 1 && !c->rccl) return FLUID_OK;      // (a one-rank communicator may be attached: it is then exercised)
@@ -72,7 +106,7 @@ int exchange(fluid_ctx* c, int kind, std::initializer_list<int> fields, int dept
     // the same field listed twice (self-advection) is exchanged once
     std::sort(ids.begin(), ids.end());
     ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
-    const int rc = c->xchg(c->xchg_user, kind, ids.data(), (int)ids.size(), depth, scalar);
+    const int rc = call_exchange(c, kind, ids.data(), (int)ids.size(), depth, scalar);
     if (rc != 0) return fail(FLUID_E_COMM, "exchange callback failed (kind %d, rc %d)", kind, rc);
     return FLUID_OK;
 }
@@ -254,7 +288,8 @@ void wrote(fluid_ctx* c, int f, int reach)
     c->src_of[f] = 0;
 }
 
-int need_list(fluid_ctx* c, const std::vector<int>& fields, int reach)
+// `async`: the compute stream does not wait for the rows (call_exchange); the caller's next solve joins them (xchg_join)
+int need_list(fluid_ctx* c, const std::vector<int>& fields, int reach, bool async = false)
 {
     if (c->nranks == 1 || reach <= 0) return FLUID_OK;
     if (reach > exchange_cap(c)) return fail(FLUID_E_COMM, "halo of %d rows exceeds the slab height", reach);
@@ -266,16 +301,16 @@ int need_list(fluid_ctx* c, const std::vector<int>& fields, int reach)
     std::sort(ids.begin(), ids.end());
     ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
     c->in_halo_exchange = true;            // rows travel as they are in memory; a pending increment stays pending on every rank alike
-    const int rc = c->xchg(c->xchg_user, FLUID_XCHG_HALO, ids.data(), (int)ids.size(), reach, nullptr);
+    const int rc = call_exchange(c, FLUID_XCHG_HALO, ids.data(), (int)ids.size(), reach, nullptr, async);
     c->in_halo_exchange = false;
     if (rc != 0) return fail(FLUID_E_COMM, "halo exchange failed (rc %d)", rc);
     for (int f : ids) c->reach[f] = reach;
     return FLUID_OK;
 }
 
-int need(fluid_ctx* c, std::initializer_list<int> fields, int reach)
+int need(fluid_ctx* c, std::initializer_list<int> fields, int reach, bool async = false)
 {
-    return need_list(c, std::vector<int>(fields), reach);
+    return need_list(c, std::vector<int>(fields), reach, async);
 }
 
 // interior rows [lo,hi) this slab computes when it works `reach` rows past its inner edges
@@ -610,8 +645,10 @@ struct DivSource {
     float scale;          // -0.5f * h
 };
 
+// `keep_pending`: an exchange the caller issued async feeds another batch on another stream too -- this batch joins it on
+// its own stream but leaves it marked as in flight (full_step: the density diffusion beside the velocity path)
 int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int final_reach = 0, const DivSource* ds = nullptr,
-                     int scratch_base = 0)
+                     int scratch_base = 0, bool keep_pending = false)
 {
     static const int kScratchAll[3] = {FLUID_TMP0, FLUID_TMP1, FLUID_TMP2};
     static const int kSumAll[3] = {FLUID_TMP3, FLUID_TMP4, FLUID_TMP5};      // x0 + dt*s of a deferred add_source lands here
@@ -628,6 +665,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 return fail(FLUID_E_INVALID, "diffuse: the solves of a batch must not share fields");
     }
     if (iters == 0) {
+        TRY(xchg_join(c, keep_pending));
         for (int k = 0; k < count; ++k) TRY(settle_source(c, sv[k].x0));    // (no launch to take a deferred source over)
         return FLUID_OK;
     }
@@ -662,7 +700,11 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
         const int T0 = pick_sweeps(c, iters, iters, canonical0, small0, cells0, all_mode4);
         add_src = add_src && same_mode && fluid::jacobi_tb_addsrc_exists(T0, divmode[0], c->tb_nv);
         if (!add_src)
-            for (int k = 0; k < count; ++k) TRY(settle_source(c, sv[k].x0));
+            for (int k = 0; k < count; ++k)
+                if (c->src_of[sv[k].x0]) {
+                    TRY(xchg_join(c, keep_pending));                        // (its kernel touches rows that may be on their way)
+                    TRY(settle_source(c, sv[k].x0));
+                }
     }
     // division mode 3 needs |x0| >= beta * 2^-72 wherever it is used: minima of |x0| per tile, once per solve (x0 does not
     // change during it), over the rows of x0 that are valid here; tiles beyond them read 0 = "divide the long way"
@@ -679,6 +721,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 ++m;
             }
         if (m > 0) {
+            TRY(xchg_join(c, keep_pending));
             if (c->nranks > 1)
                 HIP_TRY(hipMemsetAsync(c->tiles + (size_t)scratch_base * tile_words, 0, (size_t)count * tile_words * sizeof(unsigned), c->stream));
             int lo, hi;
@@ -716,18 +759,22 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 ids.push_back(cur[j]);
                 if (c->reach[sv[j].x0] < depth - 1) ids.push_back(sv[j].x0);
             }
-            TRY(need_list(c, ids, depth));
+            TRY(xchg_join(c, keep_pending));                                  // (the caller's exchange first, if it is still out)
+            TRY(need_list(c, ids, depth, /*async=*/true));                    // the launch below is split around it
+            keep_pending = false;                                             // (this one is this batch's own)
             r = reach_now();
         }
         const int T = canonical ? wantT : pick(std::min(r, remaining));
         if (add_src && k == 0 && !fluid::jacobi_tb_addsrc_exists(T, divmode[0], c->tb_nv)) {
             add_src = false;                   // a shallower first launch than planned (short reach): the kernel of its own after all
+            TRY(xchg_join(c, keep_pending));
             for (int j = 0; j < count; ++j) TRY(settle_source(c, sv[j].x0));
         }
         int lo, hi;
         rows(c, multi ? std::min(r - T, exchange_cap(c)) : 0, &lo, &hi);
         if (T == 1) {
             const int v = c->variant == fluid::JACOBI_TB ? (small ? fluid::JACOBI_NAIVE : fluid::JACOBI_STREAM) : c->variant;
+            TRY(xchg_join(c, keep_pending));
             for (int j = 0; j < count; ++j) TRY(materialize(c, cur[j]));      // single-sweep kernels read x
             for (int j = 0; j < count; ++j) TRY(settle(c, sv[j].x0));         // ... and x0 as it is in memory
             for (int j = 0; j < count; ++j)
@@ -777,46 +824,69 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                     bt.div_scale = ds->scale;
                     bt.x0_inc[0] = -0.0f;
                 }
-                int rb = c->tb_rows;
                 const int edge_pct = c->tb_edge_pct > 0 ? c->tb_edge_pct : 100;
                 auto edge_rows = [&](int r) { return std::max(2 * T, r * edge_pct / 100); };
-                if (rb <= 0) {
-                    // auto (tools/tb_sweep.py on MI355X): the kernel hides its latencies only behind other
-                    // waves, so it wants every block resident at once -- a 256-thread block is one wave per
-                    // SIMD, tb_waves_per_simd blocks fit a CU -- and then the tallest strips that still
-                    // allow (each strip pays 2T rows of pipeline fill).  Smallest strip height whose
-                    // non-empty blocks fit 92 % of one round; grids too large for one round stop at 80
-                    // rows (160 for a batch; 192 at T = 16), past which more strips win again.
-                    const int nv = c->tb_nv;
-                    const int HL = (T + nv - 1) / nv, VS = 64 - 2 * HL;
-                    const long long windows = ((c->n + nv - 1) / nv + VS - 1) / VS;
-                    const int resident = nv == 2 ? (T >= 16 ? 2 : 4) : (T >= 8 ? 2 : 3);
-                    const long long room = (long long)c->num_cu * resident * 92 / 100;
-                    const long long rows_n = hi - lo;
-                    auto blocks = [&](int r) {
-                        const long long si = (rows_n + r - 1) / r, se = (rows_n + edge_rows(r) - 1) / edge_rows(r);
-                        const long long inner = windows > 2 ? windows - 2 : 0, outer = windows - inner;
-                        return (inner * ((si + 3) / 4) + outer * ((se + 3) / 4)) * m;
-                    };
-                    const int cap = T >= 16 ? 192 : (T >= 8 ? 80 : 96) * (m > 1 ? 2 : 1);
-                    rb = 2 * T;
-                    while (rb < cap && blocks(rb) > room) rb += 2;
-                    // small grids: a launch lasts as long as one wave's march of rb + 2T rows, and the best height
-                    // measured is about rows / 64 (2 at 128^2, 4 at 256^2, 8 at 512^2, 16 and more from 1024^2)
-                    if (rows_n <= 1100) rb = std::max(2, std::min(rb, (int)(rows_n / 64) & ~1));
+                // this launch on output rows [lo_, hi_) (the whole launch, or one part of a launch split around an exchange)
+                auto launch_rows = [&](int lo_, int hi_) -> int {
+                    int rb = c->tb_rows;
+                    if (rb <= 0) {
+                        // auto (tools/tb_sweep.py on MI355X): the kernel hides its latencies only behind other
+                        // waves, so it wants every block resident at once -- a 256-thread block is one wave per
+                        // SIMD, tb_waves_per_simd blocks fit a CU -- and then the tallest strips that still
+                        // allow (each strip pays 2T rows of pipeline fill).  Smallest strip height whose
+                        // non-empty blocks fit 92 % of one round; grids too large for one round stop at 80
+                        // rows (160 for a batch; 192 at T = 16), past which more strips win again.
+                        const int nv = c->tb_nv;
+                        const int HL = (T + nv - 1) / nv, VS = 64 - 2 * HL;
+                        const long long windows = ((c->n + nv - 1) / nv + VS - 1) / VS;
+                        const int resident = nv == 2 ? (T >= 16 ? 2 : 4) : (T >= 8 ? 2 : 3);
+                        const long long room = (long long)c->num_cu * resident * 92 / 100;
+                        const long long rows_n = hi_ - lo_;
+                        auto blocks = [&](int r) {
+                            const long long si = (rows_n + r - 1) / r, se = (rows_n + edge_rows(r) - 1) / edge_rows(r);
+                            const long long inner = windows > 2 ? windows - 2 : 0, outer = windows - inner;
+                            return (inner * ((si + 3) / 4) + outer * ((se + 3) / 4)) * m;
+                        };
+                        const int cap = T >= 16 ? 192 : (T >= 8 ? 80 : 96) * (m > 1 ? 2 : 1);
+                        rb = 2 * T;
+                        while (rb < cap && blocks(rb) > room) rb += 2;
+                        // small grids: a launch lasts as long as one wave's march of rb + 2T rows, and the best height
+                        // measured is about rows / 64 (2 at 128^2, 4 at 256^2, 8 at 512^2, 16 and more from 1024^2)
+                        if (rows_n <= 1100) rb = std::max(2, std::min(rb, (int)(rows_n / 64) & ~1));
+                    }
+                    // ... and that closed form is only the first candidate of the run-time tuner (see RbTuner)
+                    int trial = -1;
+                    unsigned long long key = 0;
+                    if (c->tb_rows <= 0 && c->autotune) {
+                        key = tune_key(c, T, m + (divsrc ? 8 : 0) + (addsrc ? 16 : 0), divmode[first], hi_ - lo_);
+                        rb = tune_pick(c, key, rb, T, hi_ - lo_, &trial);
+                    }
+                    // edge windows (ghost columns) cost ~1.6x per row: shorter strips there keep the launch balanced
+                    const int rb_edge = std::min(rb, edge_rows(rb));
+                    if (trial >= 0) TRY(tune_begin(c, key, trial));
+                    fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], c->tb_nv, bt, c->pitch, c->n, lo_, hi_, rb, rb_edge, divsrc, addsrc);
+                    if (trial >= 0) TRY(tune_end(c));
+                    return FLUID_OK;
+                };
+                // An exchange is still in flight (issued async just above, or by the caller): the strips whose inputs are this
+                // slab's own rows -- output rows [own0 + T, own1 - T): T sweeps reach T rows -- go first and run while the halo
+                // rows travel; the strips next to the slab's inner edges wait for the exchange's event.  Same arithmetic per
+                // cell whichever launch it falls into.
+                int in_lo = lo, in_hi = hi;
+                if (c->xpend && multi) {
+                    if (c->rank > 0) in_lo = std::max(lo, c->own0 + T);
+                    if (c->rank < c->nranks - 1) in_hi = std::min(hi, c->own1 - T);
                 }
-                // ... and that closed form is only the first candidate of the run-time tuner (see RbTuner)
-                int trial = -1;
-                unsigned long long key = 0;
-                if (c->tb_rows <= 0 && c->autotune) {
-                    key = tune_key(c, T, m + (divsrc ? 8 : 0) + (addsrc ? 16 : 0), divmode[first], hi - lo);
-                    rb = tune_pick(c, key, rb, T, hi - lo, &trial);
+                if (c->xpend && in_hi - in_lo >= 2 * T && (in_lo > lo || in_hi < hi)) {
+                    TRY(launch_rows(in_lo, in_hi));
+                    TRY(xchg_join(c, keep_pending));
+                    if (in_lo > lo) TRY(launch_rows(lo, in_lo));
+                    if (in_hi < hi) TRY(launch_rows(in_hi, hi));
+                    c->split_launches += 1;
+                } else {
+                    TRY(xchg_join(c, keep_pending));
+                    TRY(launch_rows(lo, hi));
                 }
-                // edge windows (ghost columns) cost ~1.6x per row: shorter strips there keep the launch balanced
-                const int rb_edge = std::min(rb, edge_rows(rb));
-                if (trial >= 0) TRY(tune_begin(c, key, trial));
-                fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], c->tb_nv, bt, c->pitch, c->n, lo, hi, rb, rb_edge, divsrc, addsrc);
-                if (trial >= 0) TRY(tune_end(c));
                 if (c->timing) {
                     c->launches += 1;
                     c->field_launches += m;
@@ -1084,7 +1154,7 @@ int project(fluid_ctx* c, int u, int v, int p, int div, int iters, const AdvectA
         if (p == u || p == v || div == u || div == v || p == div)
             return fail(FLUID_E_INVALID, "divergence: outputs must not alias inputs");
         TRY(materialize(c, {u, v}));
-        if (c->nranks > 1) TRY(need(c, {u, v}, reach + 1));
+        if (c->nranks > 1) TRY(need(c, {u, v}, reach + 1, /*async=*/true));      // joined by the solve's first launch
         mark_zero(c, p);
         c->zero[div] = false;               // about to be overwritten entirely
         c->pend[div] = false;
@@ -1094,6 +1164,7 @@ int project(fluid_ctx* c, int u, int v, int p, int div, int iters, const AdvectA
         const int rc = op_diffuse(c, 0, p, div, 1.0f, 4.0f, iters, /*final_reach=*/1, &ds);
         c->in_pressure_solve = false;
         TRY(rc);
+        TRY(xchg_join(c));
         wrote(c, div, 0);
         if (then_advect) return op_gradient_advect(c, u, v, p, then_advect->b, then_advect->d, then_advect->d0, then_advect->dt);
         return op_subtract_gradient(c, u, v, p, with_max);
@@ -1118,9 +1189,10 @@ int vel_step(fluid_ctx* c, float dt, float visc, int iters)
     coefficients(c->n, dt, visc, &alpha, &beta);
     // one exchange feeds both solves: right-hand sides iters-1 rows out, first guesses iters rows
     const int h = std::min(iters, c->halo);
-    TRY(need(c, {U, V, U0, V0}, h));
+    TRY(need(c, {U, V, U0, V0}, h, /*async=*/true));
     const Solve uv[2] = {{1, U0, U, alpha, beta}, {2, V0, V, alpha, beta}};
     TRY(op_diffuse_batch(c, uv, 2, iters));
+    TRY(xchg_join(c));
     TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters, nullptr, /*with_max=*/true));
     const float dt0 = dt * (float)c->n;
     TRY(vmax_begin(c, U0, V0, /*have_max=*/true));
@@ -1151,8 +1223,9 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
     TRY(op_add_source(c, U, U0, dt, /*defer=*/true));
     TRY(op_add_source(c, V, V0, dt, /*defer=*/true));
     TRY(op_add_source(c, D, D0, dt, /*defer=*/true));
-    // right-hand sides and first guesses together (zeroed sources are valid everywhere and skipped)
-    TRY(need(c, {U, V, D, U0, V0, D0}, std::min(iters, c->halo)));
+    // right-hand sides and first guesses together (zeroed sources are valid everywhere and skipped); async: the first launch
+    // of the diffusion runs its interior strips while the rows travel (op_diffuse_batch)
+    TRY(need(c, {U, V, D, U0, V0, D0}, std::min(iters, c->halo), /*async=*/true));
     float av, bv, ad, bd;
     coefficients(c->n, dt, visc, &av, &bv);
     coefficients(c->n, dt, diff, &ad, &bd);
@@ -1202,7 +1275,7 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
         HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         hipStream_t main_stream = c->stream;
         c->stream = c->stream2;
-        const int rc_dens = op_diffuse_batch(c, all + 2, 1, iters, 0, nullptr, /*scratch_base=*/2);
+        const int rc_dens = op_diffuse_batch(c, all + 2, 1, iters, 0, nullptr, /*scratch_base=*/2, /*keep_pending=*/true);
         hipError_t e_join = rc_dens == FLUID_OK ? hipEventRecord(c->ev_join, c->stream2) : hipSuccess;
         c->stream = main_stream;
         TRY(rc_dens);
@@ -1219,6 +1292,7 @@ int full_step(fluid_ctx* c, float dt, float diff, float visc, int iters)
     const int rest = fill1 + fill2, head = iters - rest;
     if (head > 0) TRY(op_diffuse_batch(c, all, 3, head));
     if (rest > 0) TRY(op_diffuse_batch(c, all, 2, rest));
+    TRY(xchg_join(c));
     TRY(project(c, U0, V0, /*p=*/U, /*div=*/V, iters, nullptr, /*with_max=*/true));
     TRY(vmax_begin(c, U0, V0, /*have_max=*/true));
     if (fill1 > 0) TRY(op_diffuse_batch(c, all + 2, 1, fill1));
@@ -1397,6 +1471,9 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
         if (!hip_ok(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking), "hipStreamCreate(second stream)")) return bail(rc);
         if (!hip_ok(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate")) return bail(rc);
         if (!hip_ok(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreate")) return bail(rc);
+        if (!hip_ok(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking), "hipStreamCreate(exchange stream)")) return bail(rc);
+        if (!hip_ok(hipEventCreateWithFlags(&c->ev_xbegin, hipEventDisableTiming), "hipEventCreate")) return bail(rc);
+        if (!hip_ok(hipEventCreateWithFlags(&c->ev_xdone, hipEventDisableTiming), "hipEventCreate")) return bail(rc);
     }
     if (!hip_ok(hipMemsetAsync(c->arena, 0, bytes, c->stream), "hipMemsetAsync(arena)")) return bail(rc);
     c->d_scalar = reinterpret_cast<unsigned int*>(c->arena + c->field_bytes * FLUID_NFIELDS);   // RCCL-addressable
@@ -1428,6 +1505,7 @@ int fluid_destroy(fluid_ctx* c)
     if (!c) return FLUID_OK;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);
     for (auto& p : c->ev_pool) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -1451,6 +1529,9 @@ int fluid_destroy(fluid_ctx* c)
     if (c->scalar_ready) (void)hipEventDestroy(c->scalar_ready);
     if (c->own_arena && c->arena) (void)hipFree(c->arena);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
+    if (c->ev_xbegin) (void)hipEventDestroy(c->ev_xbegin);
+    if (c->ev_xdone) (void)hipEventDestroy(c->ev_xdone);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1463,6 +1544,22 @@ int fluid_synchronize(fluid_ctx* c)
 {
     TRY(check_ctx(c));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return FLUID_OK;
+}
+
+int fluid_exchange_stream(fluid_ctx* c, void** stream)
+{
+    TRY(check_ctx(c));
+    if (!stream) return fail(FLUID_E_INVALID, "null pointer");
+    *stream = c->stream;                    // inside an exchange callback: the exchange stream (call_exchange)
+    return FLUID_OK;
+}
+
+int fluid_split_launches(fluid_ctx* c, long long* count)
+{
+    TRY(check_ctx(c));
+    if (!count) return fail(FLUID_E_INVALID, "null pointer");
+    *count = c->split_launches;
     return FLUID_OK;
 }
 
@@ -1584,6 +1681,10 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
     case FLUID_PARAM_FUSE_ADD_SOURCE:
         c->fuse_add_source = value != 0;
         return FLUID_OK;
+    case FLUID_PARAM_XCHG_OVERLAP:
+        TRY(xchg_join(c));
+        c->xchg_overlap = value != 0;
+        return FLUID_OK;
     case FLUID_PARAM_TB_T16_MIN_CELLS:
         if (value < -1) return fail(FLUID_E_INVALID, "TB_T16_MIN_CELLS must be >= 0, or -1 for the default rule");
         c->tb_t16_min_cells = value;
@@ -1671,7 +1772,7 @@ int fluid_exchange_now(fluid_ctx* c, int kind, const int* fields, int nfields, i
         TRY(settle(c, fields[k]));             // the caller is about to look at the rows: no increment may stay pending
     }
     c->in_halo_exchange = true;
-    const int rc = c->xchg(c->xchg_user, kind, fields, nfields, depth, nullptr);
+    const int rc = call_exchange(c, kind, fields, nfields, depth, nullptr);
     c->in_halo_exchange = false;
     if (rc != 0) return fail(FLUID_E_COMM, "exchange failed (kind %d, rc %d)", kind, rc);
     for (int k = 0; k < nfields; ++k)

@@ -36,12 +36,14 @@ class TorchExchange:
     placed right now (fields may trade buffers inside a solve); rows of it are
     contiguous, so a halo needs no packing."""
 
-    def __init__(self, fields, n, rank, nranks, group=None, stream=None):
+    def __init__(self, fields, n, rank, nranks, group=None, stream=None, stream_of=None):
         if not callable(fields):
             table = fields
             fields = table.__getitem__
         self.fields, self.n, self.rank, self.nranks, self.group = fields, n, rank, nranks, group
         self.stream = stream        # torch.cuda.Stream the solver's kernels run on (None: CPU tensors)
+        self.stream_of = stream_of  # () -> hipStream_t the library wants this exchange on (its exchange stream), or None
+        self._ext = {}
         self.lo, self.hi = slab_rows(n, rank, nranks)
         self.calls = {capi.XCHG_HALO: 0, capi.XCHG_GATHER: 0, capi.XCHG_MAX: 0}
         # RCCL moves device memory directly.  gloo cannot, so device rows are
@@ -60,7 +62,16 @@ class TorchExchange:
         # collectives must order against the solver's kernels: make its stream
         # torch's current stream for the duration of the exchange
         if self.stream is not None:
-            with torch.cuda.stream(self.stream):
+            stream = self.stream
+            if self.stream_of is not None:
+                # the library runs exchanges on a stream of its own (FLUID_PARAM_XCHG_OVERLAP), ordered against its kernels by
+                # events: enqueue there, so that the first launch of the solve can run beside the rows in flight
+                ptr = self.stream_of()
+                if ptr and ptr != self.stream.cuda_stream:
+                    stream = self._ext.get(ptr)
+                    if stream is None:
+                        stream = self._ext[ptr] = torch.cuda.ExternalStream(ptr, device=self.stream.device)
+            with torch.cuda.stream(stream):
                 return self._dispatch(kind, ids, depth, scalar)
         return self._dispatch(kind, ids, depth, scalar)
 
@@ -194,7 +205,8 @@ class SlabSolver(FluidSolver):
                 hello = torch.ones(1, device=self.device)
                 dist.all_reduce(hello, group=group)
                 torch.cuda.synchronize(self.device)
-            self.exchange = TorchExchange(self.field_tensor, n, rank, nranks, group, stream=self.torch_stream)
+            self.exchange = TorchExchange(self.field_tensor, n, rank, nranks, group, stream=self.torch_stream,
+                                          stream_of=self.exchange_stream)
             off = self.scalar_ptr() - self.arena.data_ptr()
             self.exchange.set_scalar(self.arena[off:off + 4].view(torch.int32))
             self.set_exchange(self.exchange)

@@ -188,6 +188,18 @@ class FluidSolver:
                                                    check_every, C.byref(it), C.byref(res)))
         return it.value, res.value
 
+    def split_launches(self):
+        """Jacobi launches that ran as interior + edge strips around an exchange in flight (row slabs)."""
+        m = C.c_longlong()
+        capi.check(capi.lib().fluid_split_launches(self._h, C.byref(m)))
+        return m.value
+
+    def exchange_stream(self):
+        """hipStream_t (as an integer) an exchange callback should enqueue on right now."""
+        p = C.c_void_p()
+        capi.check(capi.lib().fluid_exchange_stream(self._h, C.byref(p)))
+        return p.value or 0
+
     def set_exchange(self, fn):
         """fn(kind, fields, depth, scalar_or_None) -> new scalar or None; raises on failure."""
         if fn is None:

@@ -93,6 +93,11 @@ enum {
                                       added by the first launch of the diffusion that consumes the sum (which reads both
                                       operands anyway: the source is its first guess) and stored out of place, instead of
                                       by a pass of its own over the field; 0: add_source as its own kernel.  Speed only. */
+    ,FLUID_PARAM_XCHG_OVERLAP = 13 /* 1 (default): on row slabs every exchange is enqueued on a stream of its own, ordered against
+                                      the compute stream by events, and the halo exchange that feeds a Jacobi solve is not
+                                      waited for at once: the solve's first launch runs the strips that need this slab's own
+                                      rows only while the rows travel, and the strips next to the slab's edges behind the
+                                      exchange's event.  0: exchanges in line on the context's stream.  Speed only.   */
     ,FLUID_PARAM_TB_MIN_CELLS = 4  /* FLUID_JACOBI_TB fuses sweeps only on slabs of at least this many cells
                                       (default 0: always); smaller ones run one-thread-per-cell sweeps   */
 };
@@ -264,6 +269,13 @@ enum { FLUID_XCHG_HALO = 0, FLUID_XCHG_GATHER = 1, FLUID_XCHG_MAX = 2, FLUID_XCH
 typedef int (*fluid_exchange_fn)(void *user, int kind, const int *fields, int nfields,
                                  int depth, float *scalar);
 int fluid_set_exchange(fluid_ctx *ctx, fluid_exchange_fn fn, void *user);
+/* The stream (hipStream_t) an exchange callback should enqueue on, asked from INSIDE the callback: with
+ * FLUID_PARAM_XCHG_OVERLAP the library runs its exchanges on a stream of their own (already ordered behind the kernels that
+ * produced the rows; the library orders the consumers behind it).  A callback that keeps using the stream given to
+ * fluid_create_ex stays correct -- it is merely not overlapped with compute. */
+int fluid_exchange_stream(fluid_ctx *ctx, void **stream);
+/* Jacobi launches so far that ran as interior strips + edge strips around an exchange in flight (diagnostic). */
+int fluid_split_launches(fluid_ctx *ctx, long long *count);
 /* Runs the installed exchange now for the listed fields (HALO with `depth` rows, or GATHER): how a caller collects a
  * whole field on every rank, and how the transport can be exercised on its own. */
 int fluid_exchange_now(fluid_ctx *ctx, int kind, const int *fields, int nfields, int depth);

@@ -183,6 +183,38 @@ def test_steps_bit_identical_to_one_gpu(n, nranks, halo, jacobi):
         assert kinds.count(capi.XCHG_HALO) <= 3 * 5
 
 
+@pytest.mark.parametrize("n,nranks,halo,iters", [(1022, 2, 42, 40), (1022, 4, 0, 40), (510, 3, 8, 40), (1022, 8, 20, 20)])
+def test_first_launches_split_around_the_exchange(n, nranks, halo, iters):
+    """FLUID_PARAM_XCHG_OVERLAP (exchange / compute overlap): the halo exchange that feeds a solve is issued without the
+    compute stream waiting for it; the solve's next launch runs its interior strips -- output rows [own0 + T, own1 - T), whose
+    inputs are the slab's own rows -- first, and the strips at the slab's inner edges behind the exchange's event.  Every cell
+    goes through the same arithmetic whichever part it falls into: three steps must equal the single context bit for bit,
+    with the split on (and actually happening: the counter) and off."""
+    from fluidsimulationcuda_amd import capi
+    fields = synthetic(n, seed=5)
+    splits = {}
+
+    def body(s):
+        s.step(1, use_sources=True, iters=iters)
+        s.step(2, iters=iters)
+        splits[s.rank] = s.split_launches()
+
+    want = single(n, fields, body)
+    assert splits[0] == 0                                  # one context: nothing to split around
+    for overlap in (1, 0):
+        splits.clear()
+        got, fab = run_ranks(n, nranks, halo, fields, body, jacobi=3, params={capi.PARAM_XCHG_OVERLAP: overlap})
+        for k in ("u", "v", "dens", "u_prev", "v_prev", "dens_prev"):
+            assert_bit_equal(got[k], want[k], "%s, %d slabs halo %d, overlap %d" % (k, nranks, halo, overlap))
+        for r in range(1, nranks):
+            assert fab.log[r] == fab.log[0], "rank %d issued a different exchange sequence" % r
+        if overlap:
+            # per step at least: the diffusion's first launch(es) and the first launch of each projection's solve
+            assert all(v >= 3 * 3 for v in splits.values()), splits
+        else:
+            assert all(v == 0 for v in splits.values()), splits
+
+
 @pytest.mark.parametrize("min_cells", [31 * 126 + 1, 32 * 126, 32 * 126 * 3 - 5])
 def test_uneven_slabs_take_the_same_decisions(min_cells):
     """126 rows over 4 ranks = slabs of 32, 32, 31, 31 rows.  Size-dependent choices (fuse sweeps or not,
