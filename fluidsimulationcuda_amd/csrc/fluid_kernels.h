@@ -43,7 +43,7 @@ void launch_add_source(hipStream_t s, int st, void* x, const void* src, int pitc
 void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void* x0, void* out, int pitch, int n,
                    int row_lo, int row_hi, float alpha, float beta, int b);
 void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const TbBatch& batch, int pitch, int n, int row_lo,
-                      int row_hi, int rb, int rb_edge, bool divsrc = false, bool addsrc = false);
+                      int row_hi, int rb, int rb_edge, bool divsrc = false, bool addsrc = false, int hole_lo = 0, int hole_hi = 0);
 // the launches that exist with addsrc: 2-column lanes, 8 / 12 / 16 sweeps, division modes 0, 2 and 5
 inline bool jacobi_tb_addsrc_exists(int T, int divmode, int nv) { return nv == 2 && (T == 8 || T == 12 || T == 16) && (divmode == 0 || divmode == 2 || divmode == 5); }
 // tiles of kTileRows x kTileCols interior cells, tile (r, c) = rows 1 + r*kTileRows.., columns 1 + c*kTileCols..

@@ -944,6 +944,8 @@ __device__ __forceinline__ bool tb_march_any(bool edge, bool wall, int t0, int t
 // which (window, strip group) pairs exist (launch_jacobi_tb)
 struct TbGrid {
     int inner_wins, inner_blocks, edge_wins, edge_blocks, first_right;
+    int hole_lo, hole_hi;     // rows [hole_lo, hole_hi) inside [row_lo, row_hi) are left out (hole_lo >= hole_hi: none): the two
+                              // edge parts of a launch split around a halo exchange run as ONE launch (launch_jacobi_tb)
 };
 
 // waves per SIMD the register allocator must leave room for (second launch-bound argument): the
@@ -1005,9 +1007,15 @@ __global__ __launch_bounds__(256, tb_waves_per_simd(T, NV)) void k_jacobi_tb(TbB
     a.k.lo = batch.lo[blockIdx.z];
     a.k.hi = batch.hi[blockIdx.z];
     a.x0_inc = batch.x0_inc[blockIdx.z];
-    a.q_lo = row_lo + strip * rbw;                       // this wave's output rows [q_lo, q_hi)
-    if (a.q_lo >= row_hi) return;                        // wave-uniform
-    a.q_hi = min(a.q_lo + rbw, row_hi);
+    int seg_hi = row_hi;                                 // this wave's output rows [q_lo, q_hi): strips do not straddle the hole
+    a.q_lo = row_lo + strip * rbw;
+    if (g.hole_lo < g.hole_hi) {
+        const int top = (g.hole_lo - row_lo + rbw - 1) / rbw;      // strips above the hole
+        if (strip < top) seg_hi = g.hole_lo;
+        else a.q_lo = g.hole_hi + (strip - top) * rbw;
+    }
+    if (a.q_lo >= seg_hi) return;                        // wave-uniform
+    a.q_hi = min(a.q_lo + rbw, seg_hi);
     a.s_lo = a.q_lo == 1 ? 0 : a.q_lo;                   // (ADDSRC) the strips next to a wall store the wall row too
     a.s_hi = a.q_hi == n + 1 ? n + 2 : a.q_hi;
     const int k = win * VS - HL + lane;                  // vector index: columns 1+NV*k .. NV+NV*k
@@ -1589,10 +1597,14 @@ void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void
 // 3: hi, lo = the two-term reciprocal where the tiles of |x0| minima allow it, yd elsewhere;
 // 5: beta = RN32(1/beta), hi = beta * 2^24, lo = -(RN32(1/beta) * 2^-24), yd for the second pass of a wave that met inf / NaN.
 void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const TbBatch& batch, int pitch, int n, int row_lo,
-                      int row_hi, int rb, int rb_edge, bool divsrc, bool addsrc)
+                      int row_hi, int rb, int rb_edge, bool divsrc, bool addsrc, int hole_lo, int hole_hi)
 {
     const int rows = row_hi - row_lo;
     if (rows <= 0 || batch.count <= 0) return;
+    if (hole_lo < row_lo) hole_lo = row_lo;
+    if (hole_hi > row_hi) hole_hi = row_hi;
+    const bool hole = hole_lo < hole_hi;
+    if (hole && hole_lo == row_lo && hole_hi == row_hi) return;
     if (T == 16 || T == 12) nv = 2;
     const int HL = (T + nv - 1) / nv, VS = 64 - 2 * HL;
     const unsigned nvec = (n + nv - 1) / nv;
@@ -1606,8 +1618,12 @@ void launch_jacobi_tb(hipStream_t s, int st, int T, int divmode, int nv, const T
     g.first_right = first_right;
     g.inner_wins = first_right - 1;
     g.edge_wins = 1 + (nwin - first_right);
-    g.inner_blocks = g.inner_wins * (int)cdiv(cdiv(rows, rb), 4);
-    g.edge_blocks = g.edge_wins * (int)cdiv(cdiv(rows, rb_edge), 4);
+    // strips of a window: over the rows, or over the part above the hole and the part below it (none straddles it)
+    auto strips = [&](int r) { return hole ? cdiv(hole_lo - row_lo, r) + cdiv(row_hi - hole_hi, r) : cdiv(rows, r); };
+    g.hole_lo = hole ? hole_lo : 0;
+    g.hole_hi = hole ? hole_hi : 0;
+    g.inner_blocks = g.inner_wins * (int)cdiv(strips(rb), 4);
+    g.edge_blocks = g.edge_wins * (int)cdiv(strips(rb_edge), 4);
     const dim3 grid(8 * cdiv(g.inner_blocks + g.edge_blocks, 8), 1, batch.count), block(256);
 #define FLUID_TB2(TT, DD, NN) \
     FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_jacobi_tb<TT, DD, NN, S>), grid, block, 0, s, batch, pitch, n, row_lo, row_hi, rb, rb_edge, g))

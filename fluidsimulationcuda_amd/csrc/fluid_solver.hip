@@ -64,18 +64,21 @@ int check_fields(const fluid_ctx* c, std::initializer_list<int> ids)
     return FLUID_OK;
 }
 
-// Every exchange goes through here.  With a comm stream (slabs) the callback runs with that stream as "the context's
-// stream": behind everything enqueued on the compute stream so far (event), and the compute stream behind it again (event)
-// -- at once, or, for an exchange issued `async`, when xchg_join() is called by whoever consumes the rows.  A callback that
-// enqueues elsewhere or waits on the host (the tests' in-process fabric, a torch.distributed exchange on its own stream) is
-// merely not overlapped.
+// Every exchange goes through here.  One issued `async` (slabs, FLUID_PARAM_XCHG_OVERLAP) runs with the exchange stream as
+// "the context's stream": behind everything enqueued on the compute stream so far (event), and the compute stream behind it
+// again only when xchg_join() is called by whoever consumes the rows.  A callback that enqueues elsewhere or waits on the
+// host (the tests' in-process fabric) is merely not overlapped.  The ranks issue their collectives in one order whichever
+// stream each goes to (RCCL serialises a communicator's operations in issue order across streams).
 int call_exchange(fluid_ctx* c, int kind, const int* ids, int count, int depth, float* scalar, bool async = false)
 {
-    if (!c->xstream || !c->xchg_overlap) return c->xchg(c->xchg_user, kind, ids, count, depth, scalar);
     if (c->xpend) {                                      // one exchange in flight at a time: the earlier one is joined first
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_xdone, 0));
         c->xpend = false;
     }
+    // An exchange the caller waits for at once stays in line on the compute stream: a hop to another stream and back
+    // costs ~10 us each way on this platform (measured: a no-op exchange routed through the second stream leaves the GPU
+    // idle for 20 us), which only an exchange that runs beside a launch can pay for.
+    if (!async || !c->xstream || !c->xchg_overlap) return c->xchg(c->xchg_user, kind, ids, count, depth, scalar);
     HIP_TRY(hipEventRecord(c->ev_xbegin, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->xstream, c->ev_xbegin, 0));
     hipStream_t compute = c->stream;
@@ -84,8 +87,7 @@ int call_exchange(fluid_ctx* c, int kind, const int* ids, int count, int depth, 
     c->stream = compute;
     if (rc != 0) return rc;
     HIP_TRY(hipEventRecord(c->ev_xdone, c->xstream));
-    if (async) c->xpend = true;
-    else HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_xdone, 0));
+    c->xpend = true;
     return 0;
 }
 
@@ -748,6 +750,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
     // driven by `reach`, which every sweep consumes alike whatever the launch depth, so they would pair up regardless.)
     const long long slab_cells = (long long)(c->nranks > 1 ? c->min_slab : c->n) * c->n;
     const bool small = (canonical ? (long long)c->n * c->n : slab_cells * count) < c->tb_min_cells;
+    bool joined = false;                  // this batch's stream has waited for the exchange in flight (if any)
     for (int k = 0; k < iters;) {
         const int remaining = iters - k;
         auto pick = [&](int room) { return pick_sweeps(c, remaining, room, canonical, small, slab_cells, all_mode4); };
@@ -762,19 +765,22 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
             TRY(xchg_join(c, keep_pending));                                  // (the caller's exchange first, if it is still out)
             TRY(need_list(c, ids, depth, /*async=*/true));                    // the launch below is split around it
             keep_pending = false;                                             // (this one is this batch's own)
+            joined = false;
             r = reach_now();
         }
         const int T = canonical ? wantT : pick(std::min(r, remaining));
         if (add_src && k == 0 && !fluid::jacobi_tb_addsrc_exists(T, divmode[0], c->tb_nv)) {
             add_src = false;                   // a shallower first launch than planned (short reach): the kernel of its own after all
-            TRY(xchg_join(c, keep_pending));
+            if (!joined) TRY(xchg_join(c, keep_pending));
+            joined = true;
             for (int j = 0; j < count; ++j) TRY(settle_source(c, sv[j].x0));
         }
         int lo, hi;
         rows(c, multi ? std::min(r - T, exchange_cap(c)) : 0, &lo, &hi);
         if (T == 1) {
             const int v = c->variant == fluid::JACOBI_TB ? (small ? fluid::JACOBI_NAIVE : fluid::JACOBI_STREAM) : c->variant;
-            TRY(xchg_join(c, keep_pending));
+            if (!joined) TRY(xchg_join(c, keep_pending));
+            joined = true;
             for (int j = 0; j < count; ++j) TRY(materialize(c, cur[j]));      // single-sweep kernels read x
             for (int j = 0; j < count; ++j) TRY(settle(c, sv[j].x0));         // ... and x0 as it is in memory
             for (int j = 0; j < count; ++j)
@@ -827,7 +833,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 const int edge_pct = c->tb_edge_pct > 0 ? c->tb_edge_pct : 100;
                 auto edge_rows = [&](int r) { return std::max(2 * T, r * edge_pct / 100); };
                 // this launch on output rows [lo_, hi_) (the whole launch, or one part of a launch split around an exchange)
-                auto launch_rows = [&](int lo_, int hi_) -> int {
+                auto launch_rows = [&](int lo_, int hi_, int hole_lo = 0, int hole_hi = 0) -> int {
                     int rb = c->tb_rows;
                     if (rb <= 0) {
                         // auto (tools/tb_sweep.py on MI355X): the kernel hides its latencies only behind other
@@ -841,7 +847,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                         const long long windows = ((c->n + nv - 1) / nv + VS - 1) / VS;
                         const int resident = nv == 2 ? (T >= 16 ? 2 : 4) : (T >= 8 ? 2 : 3);
                         const long long room = (long long)c->num_cu * resident * 92 / 100;
-                        const long long rows_n = hi_ - lo_;
+                        const long long rows_n = (hi_ - lo_) - std::max(0, hole_hi - hole_lo);
                         auto blocks = [&](int r) {
                             const long long si = (rows_n + r - 1) / r, se = (rows_n + edge_rows(r) - 1) / edge_rows(r);
                             const long long inner = windows > 2 ? windows - 2 : 0, outer = windows - inner;
@@ -858,13 +864,16 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                     int trial = -1;
                     unsigned long long key = 0;
                     if (c->tb_rows <= 0 && c->autotune) {
-                        key = tune_key(c, T, m + (divsrc ? 8 : 0) + (addsrc ? 16 : 0), divmode[first], hi_ - lo_);
-                        rb = tune_pick(c, key, rb, T, hi_ - lo_, &trial);
+                        // (the two edge parts of a split launch: keyed by their rows, and as a shape of their own)
+                        const long long rows_k = (hi_ - lo_) - std::max(0, hole_hi - hole_lo);
+                        key = tune_key(c, T, m + (divsrc ? 8 : 0) + (addsrc ? 16 : 0) + (hole_hi > hole_lo ? 32 : 0), divmode[first], rows_k);
+                        rb = tune_pick(c, key, rb, T, rows_k, &trial);
                     }
                     // edge windows (ghost columns) cost ~1.6x per row: shorter strips there keep the launch balanced
                     const int rb_edge = std::min(rb, edge_rows(rb));
                     if (trial >= 0) TRY(tune_begin(c, key, trial));
-                    fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], c->tb_nv, bt, c->pitch, c->n, lo_, hi_, rb, rb_edge, divsrc, addsrc);
+                    fluid::launch_jacobi_tb(c->stream, c->st, T, divmode[first], c->tb_nv, bt, c->pitch, c->n, lo_, hi_, rb, rb_edge, divsrc, addsrc,
+                                            hole_lo, hole_hi);
                     if (trial >= 0) TRY(tune_end(c));
                     return FLUID_OK;
                 };
@@ -873,20 +882,20 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
                 // rows travel; the strips next to the slab's inner edges wait for the exchange's event.  Same arithmetic per
                 // cell whichever launch it falls into.
                 int in_lo = lo, in_hi = hi;
-                if (c->xpend && multi) {
+                if (c->xpend && !joined && multi) {
                     if (c->rank > 0) in_lo = std::max(lo, c->own0 + T);
                     if (c->rank < c->nranks - 1) in_hi = std::min(hi, c->own1 - T);
                 }
-                if (c->xpend && in_hi - in_lo >= 2 * T && (in_lo > lo || in_hi < hi)) {
+                if (c->xpend && !joined && in_hi - in_lo >= 2 * T && (in_lo > lo || in_hi < hi)) {
                     TRY(launch_rows(in_lo, in_hi));
                     TRY(xchg_join(c, keep_pending));
-                    if (in_lo > lo) TRY(launch_rows(lo, in_lo));
-                    if (in_hi < hi) TRY(launch_rows(in_hi, hi));
+                    TRY(launch_rows(lo, hi, in_lo, in_hi));              // both edge parts in one launch
                     c->split_launches += 1;
                 } else {
-                    TRY(xchg_join(c, keep_pending));
+                    if (!joined) TRY(xchg_join(c, keep_pending));
                     TRY(launch_rows(lo, hi));
                 }
+                joined = true;
                 if (c->timing) {
                     c->launches += 1;
                     c->field_launches += m;

@@ -3,7 +3,8 @@
 A context configured as rank r of P with a no-op exchange callback executes the
 same kernels on the same row ranges as in a real run (the numbers it produces
 are meaningless: halos are never filled).   python tools/slab_timing.py [grid] [P] [rows...]
-environment: HALO (ghost-zone depth), STORAGE (1: fp16 fields), T16MIN (FLUID_PARAM_TB_T16_MIN_CELLS), TB_T (most sweeps per launch)"""
+environment: HALO (ghost-zone depth), STORAGE (1: fp16 fields), T16MIN (FLUID_PARAM_TB_T16_MIN_CELLS), TB_T (most sweeps per launch),
+OVERLAP (FLUID_PARAM_XCHG_OVERLAP)"""
 import os
 import sys
 import time
@@ -44,6 +45,8 @@ with F.FluidSolver(n, rank=P // 2 - 1 if P > 1 else 0, nranks=P, halo=int(os.env
         s.set_param(capi.PARAM_TB_T16_MIN_CELLS, int(os.environ["T16MIN"]))
     if os.environ.get("TB_T"):
         s.set_param(capi.PARAM_TB_MAX_SWEEPS, int(os.environ["TB_T"]))
+    if os.environ.get("OVERLAP"):
+        s.set_param(capi.PARAM_XCHG_OVERLAP, int(os.environ["OVERLAP"]))
     for rows in rows_list:
         s.set_param(capi.PARAM_TB_ROWS, rows)
         s.step(2)
