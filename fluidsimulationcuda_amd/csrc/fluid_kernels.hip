@@ -1118,7 +1118,11 @@ __global__ __launch_bounds__(256) void k_tile_min_abs(TileBatch tb, int pitch, i
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 16));
     // (the 16 lanes of a tile agree on i0 < i1; lane 0 of the group holds the tile's first column)
-    if ((lane & 15) == 0 && j <= n) out[(size_t)tr * tile_pitch + (j - 1) / kTileCols] = i0 < i1 ? __float_as_uint(m) : 0u;
+    // A tile only partly inside [row_lo, row_hi) (a slab's ghost zone ends inside it) reads 0 = "divide the long way": rows
+    // of it that become valid later -- an exchange inside the solve -- were never looked at, and a wave working on them must
+    // not take the two-term path on the strength of the rows that were.
+    const bool whole = row_lo <= 1 + tr * kTileRows && row_hi >= min(n + 1, 1 + (tr + 1) * kTileRows);
+    if ((lane & 15) == 0 && j <= n) out[(size_t)tr * tile_pitch + (j - 1) / kTileCols] = whole ? __float_as_uint(m) : 0u;
 }
 
 // ---------------------------------------------------------------------------

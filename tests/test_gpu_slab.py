@@ -292,6 +292,36 @@ def test_operators_on_slabs(variant):
         assert_bit_equal(got[k], want[k], k)
 
 
+@pytest.mark.parametrize("halo", [4, 8, 30])
+def test_two_term_division_on_slabs_with_tiny_values_in_the_neighbours_rows(oracle, halo):
+    """Division mode 3 (FAST_DIVISION = 1) takes its two-term path only where the tiles of |x0| minima allow it, and the
+    minima are taken once per solve over the rows valid at that moment.  A right-hand side that is tiny (2^-120 .. 2^-80:
+    where the two-term quotient can be an ulp off) ONLY in rows just beyond a slab's edge -- rows that become valid later,
+    through an exchange inside the solve -- must not be vouched for by the rows of the same tile that were looked at: a
+    tile only partly inside the valid rows counts as unknown.  Slabs == one context == the oracle, bit for bit."""
+    from fluidsimulationcuda_amd import capi
+    import fluidsimulationcuda_amd as F
+    n, nranks = 254, 2
+    rng = np.random.default_rng(halo)
+    alpha, beta = F.coefficients(n, DT, VISC)
+    x, x0 = rnd(rng, n), rnd(rng, n, 0.5, 1.5)
+    edge = n // nranks + 1                                   # first row of the second slab
+    for lo, hi in ((edge + 1, edge + 12), (edge - 12, edge - 1)):
+        x0[lo:hi] *= (np.float32(2.0) ** rng.integers(-120, -80, (hi - lo, n + 2))).astype(np.float32)
+    fields = {k: np.zeros((n + 2, n + 2), np.float32) for k in ("u", "v", "dens", "u_prev", "v_prev", "dens_prev")}
+    fields["u"], fields["v"] = x, x0
+
+    def body(s):
+        assert s.division_mode(alpha, beta) == 3
+        s.diffuse(1, "u", "v", alpha, beta, 40)
+
+    params = {capi.PARAM_TB_FAST_DIVISION: 1}
+    got, _ = run_ranks(n, nranks, halo, fields, body, jacobi=3, params=params)
+    want = x.copy()
+    oracle.diffuse(1, want, x0, alpha, beta, 40)
+    assert_bit_equal(got["u"], want, "two-term division on slabs, halo %d" % halo)
+
+
 def test_too_many_slabs_is_rejected():
     from fluidsimulationcuda_amd import capi
     from fluidsimulationcuda_amd.solver import FluidSolver
