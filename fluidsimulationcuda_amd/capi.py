@@ -24,6 +24,7 @@ PARAM_SLAB_OVERLAP = 10
 PARAM_EARLY_ADVECT = 11
 PARAM_FUSE_ADD_SOURCE = 12
 PARAM_XCHG_OVERLAP = 13
+PARAM_F16_PRESSURE_SCALE = 14
 XCHG_HALO, XCHG_GATHER, XCHG_MAX, XCHG_MAX_BEGIN, XCHG_MAX_END = 0, 1, 2, 3, 4
 RCCL_ID_BYTES = 128
 FIELD_NAMES = ("u", "v", "dens", "u_prev", "v_prev", "dens_prev", "tmp0", "tmp1", "tmp2", "tmp3", "tmp4", "tmp5")

@@ -88,6 +88,12 @@ struct fluid_ctx {
     int src_of[FLUID_NFIELDS] = {};           // 0: nothing owed; else 1 + the id of the source field
     float src_dt[FLUID_NFIELDS] = {};
     bool fuse_add_source = true;              // FLUID_PARAM_FUSE_ADD_SOURCE
+    // fp16 storage: the pressure of a projection is of the order h * |velocity| -- 1e-5 at 16384^2, inside fp16's subnormal
+    // range -- so inside a step the divergence and the pressure are kept multiplied by a power of two (fluid_solver.hip:
+    // project); fscale[f] is that factor for field f (1: plain values), undone exactly when the field is downloaded and by a
+    // pass over it for any reader that does not know
+    float pscale = 1.0f;
+    float fscale[FLUID_NFIELDS];
     fluid_exchange_fn xchg = nullptr;
     void* xchg_user = nullptr;
     fluid_detail::RcclExchange* rccl = nullptr;   // the library's own exchange, when attached (fluid_exchange_rccl_attach)

@@ -60,15 +60,17 @@ void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u
                    int row_lo, int row_hi, float dt0, int b);
 void launch_advect2(hipStream_t s, int st, void* da, const void* d0a, int ba, void* db, const void* d0b, int bb, const void* u,
                     const void* v, int pitch, int n, int row_lo, int row_hi, float dt0);
+// pscale: power of two the divergence is stored multiplied by (1: plain)
 void launch_divergence(hipStream_t s, int st, const void* u, const void* v, void* p, void* div, int pitch, int n,
-                       int row_lo, int row_hi, float h, int write_p);
+                       int row_lo, int row_hi, float h, int write_p, float pscale = 1.0f);
+void launch_scale(hipStream_t s, int st, void* x, int pitch, int row_lo, int row_hi, float factor);
 // max_out != nullptr: also leaves max(|u|, |v|) of the stored interior values in *max_out (the bit pattern of a
 // non-negative float; what launch_absmax2 would produce for the same rows), via `partials` (kMaxPartials floats of scratch)
 constexpr int kMaxPartials = 8192;
 void launch_subtract_gradient(hipStream_t s, int st, void* u, void* v, const void* p, int pitch, int n, int row_lo,
-                              int row_hi, float h, float* partials = nullptr, unsigned int* max_out = nullptr);
+                              int row_hi, float h, float* partials = nullptr, unsigned int* max_out = nullptr, float pinv = 1.0f);
 void launch_gradient_advect(hipStream_t s, int st, void* u, void* v, const void* p, void* d, const void* d0, int pitch, int n,
-                            int row_lo, int row_hi, float h, float dt0, int b);
+                            int row_lo, int row_hi, float h, float dt0, int b, float pinv = 1.0f);
 void launch_absmax2(hipStream_t s, int st, const void* u, const void* v, int pitch, int n, int row_lo, int row_hi,
                     unsigned int* result);
 void launch_residual(hipStream_t s, int st, const void* x, const void* x0, int pitch, int n, int row_lo, int row_hi,

@@ -208,6 +208,24 @@ __global__ __launch_bounds__(256) void k_add_zero_source(S* __restrict__ x, int 
     }
 }
 
+// x *= factor on rows [row_lo, row_hi) (factor a power of two: how a field kept scaled -- the pressure and its right-hand
+// side with fp16 storage, see fluid_solver.hip: project -- goes back to its plain values for a reader that does not know)
+template <typename S>
+__global__ __launch_bounds__(256) void k_scale(S* __restrict__ x, int pitch, int row_lo, int row_hi, float factor)
+{
+    const int nvec = pitch >> 2;
+    const size_t total = (size_t)(row_hi - row_lo) * nvec;
+    S* xv = x + (size_t)row_lo * pitch;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        float4 a = ld4(xv + 4 * t);
+        a.x = a.x * factor;
+        a.y = a.y * factor;
+        a.z = a.z * factor;
+        a.w = a.w * factor;
+        st4(xv + 4 * t, a);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // a4  Jacobi sweep, three variants.  All compute, for interior rows
 // [row_lo,row_hi) and columns 1..n,
@@ -1325,14 +1343,14 @@ __global__ __launch_bounds__(256) void k_advect2(S* __restrict__ da, const S* __
 template <typename S>
 __global__ __launch_bounds__(256) void k_divergence(const S* __restrict__ u, const S* __restrict__ v, S* __restrict__ p,
                                                     S* __restrict__ div, int pitch, int n, int row_lo, int row_hi,
-                                                    float h, int write_p)
+                                                    float h, int write_p, float pscale)
 {
     const int j = 1 + blockIdx.x * 256 + threadIdx.x;
     const int i = row_lo + blockIdx.y;
     if (j > n || i >= row_hi) return;
     const size_t P = (size_t)pitch;
     const size_t c = (size_t)i * P + XOFF + j;
-    const float scale = -0.5f * h;
+    const float scale = (-0.5f * h) * pscale;            // pscale: a power of two (1 unless the solver keeps a scaled pressure, fp16 storage)
     float g = ld1(u + c + 1) - ld1(u + c - 1);
     g = g + ld1(v + c + P);
     g = g - ld1(v + c - P);
@@ -1359,7 +1377,7 @@ __device__ __forceinline__ float wave_max(float m)
 // ---------------------------------------------------------------------------
 template <typename S>
 __global__ __launch_bounds__(256) void k_subtract_gradient(S* __restrict__ u, S* __restrict__ v, const S* __restrict__ p,
-                                                           int pitch, int n, int row_lo, int row_hi, float h)
+                                                           int pitch, int n, int row_lo, int row_hi, float h, float pinv)
 {
     const int j = 1 + blockIdx.x * 256 + threadIdx.x;
     const int i = row_lo + blockIdx.y;
@@ -1368,8 +1386,9 @@ __global__ __launch_bounds__(256) void k_subtract_gradient(S* __restrict__ u, S*
     const size_t c = (size_t)i * P + XOFF + j;
     const float gx = 0.5f * (ld1(p + c + 1) - ld1(p + c - 1));
     const float gy = 0.5f * (ld1(p + c + P) - ld1(p + c - P));
-    const float nu = ld1(u + c) - gx / h;
-    const float nv = ld1(v + c) - gy / h;
+    // pinv: 1 / (the power of two the pressure field is scaled by): (2^k x) / h * 2^-k is x / h, bit for bit
+    const float nu = ld1(u + c) - (gx / h) * pinv;
+    const float nv = ld1(v + c) - (gy / h) * pinv;
     st1(u + c, nu);
     st1(v + c, nv);
     emit_ghosts(u, P, n, 1, j, i, nu);
@@ -1383,7 +1402,7 @@ __global__ __launch_bounds__(256) void k_subtract_gradient(S* __restrict__ u, S*
 template <typename S>
 __global__ __launch_bounds__(256) void k_subtract_gradient_max(S* __restrict__ u, S* __restrict__ v, const S* __restrict__ p,
                                                                int pitch, int n, int row_lo, int row_hi, float h,
-                                                               float* __restrict__ partials)
+                                                               float* __restrict__ partials, float pinv)
 {
     const int j = 1 + blockIdx.x * 256 + threadIdx.x;
     const size_t P = (size_t)pitch;
@@ -1393,8 +1412,8 @@ __global__ __launch_bounds__(256) void k_subtract_gradient_max(S* __restrict__ u
             const size_t c = (size_t)i * P + XOFF + j;
             const float gx = 0.5f * (ld1(p + c + 1) - ld1(p + c - 1));
             const float gy = 0.5f * (ld1(p + c + P) - ld1(p + c - P));
-            const float nu = ld1(u + c) - gx / h;
-            const float nv = ld1(v + c) - gy / h;
+            const float nu = ld1(u + c) - (gx / h) * pinv;
+            const float nv = ld1(v + c) - (gy / h) * pinv;
             st1(u + c, nu);
             st1(v + c, nv);
             emit_ghosts(u, P, n, 1, j, i, nu);
@@ -1429,7 +1448,7 @@ __global__ __launch_bounds__(256) void k_max_partials(const float* __restrict__ 
 template <typename S, typename IDX>
 __global__ __launch_bounds__(256) void k_gradient_advect(S* __restrict__ u, S* __restrict__ v, const S* __restrict__ p,
                                                          S* __restrict__ d, const S* __restrict__ d0, int pitch, int n,
-                                                         int row_lo, int row_hi, float h, float dt0, int b)
+                                                         int row_lo, int row_hi, float h, float dt0, int b, float pinv)
 {
     const int j0 = advect_col0();
     const int i = row_lo + blockIdx.y;
@@ -1443,8 +1462,8 @@ __global__ __launch_bounds__(256) void k_gradient_advect(S* __restrict__ u, S* _
         const IDX c = r + (IDX)min(j0 + 64 * k, n) * E;
         const float gx = 0.5f * (ld1(at(p, c + E)) - ld1(at(p, c - E)));
         const float gy = 0.5f * (ld1(at(p, c + P)) - ld1(at(p, c - P)));
-        nu[k] = ld1(at(u, c)) - gx / h;
-        nv[k] = ld1(at(v, c)) - gy / h;
+        nu[k] = ld1(at(u, c)) - (gx / h) * pinv;
+        nv[k] = ld1(at(v, c)) - (gy / h) * pinv;
     }
 #pragma unroll
     for (int k = 0; k < kAdvectRounds; ++k) {
@@ -1568,6 +1587,13 @@ void launch_add_source(hipStream_t s, int st, void* x, const void* src, int pitc
     }
     FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_add_source<S>, dim3(blocks ? blocks : 1), dim3(256), 0, s, (S*)x,
                                             (const S*)src, pitch, row_lo, row_hi, dt));
+}
+
+void launch_scale(hipStream_t s, int st, void* x, int pitch, int row_lo, int row_hi, float factor)
+{
+    const size_t total = (size_t)(row_hi - row_lo) * (pitch >> 2);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_scale<S>, dim3(blocks ? blocks : 1), dim3(256), 0, s, (S*)x, pitch, row_lo, row_hi, factor));
 }
 
 void launch_jacobi(hipStream_t s, int st, int variant, const void* x, const void* x0, void* out, int pitch, int n,
@@ -1736,41 +1762,41 @@ void launch_advect2(hipStream_t s, int st, void* da, const void* d0a, int ba, vo
 }
 
 void launch_divergence(hipStream_t s, int st, const void* u, const void* v, void* p, void* div, int pitch, int n,
-                       int row_lo, int row_hi, float h, int write_p)
+                       int row_lo, int row_hi, float h, int write_p, float pscale)
 {
     if (row_hi <= row_lo) return;
     FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_divergence<S>, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s,
                                             (const S*)u, (const S*)v, (S*)p, (S*)div, pitch, n, row_lo, row_hi, h,
-                                            write_p));
+                                            write_p, pscale));
 }
 
 void launch_subtract_gradient(hipStream_t s, int st, void* u, void* v, const void* p, int pitch, int n, int row_lo,
-                              int row_hi, float h, float* partials, unsigned int* max_out)
+                              int row_hi, float h, float* partials, unsigned int* max_out, float pinv)
 {
     if (row_hi <= row_lo) return;
     if (max_out) {
         const unsigned per_col = cdiv(n, 256), rows = (unsigned)(row_hi - row_lo);
         const unsigned gy = std::max(1u, std::min(rows, (unsigned)kMaxPartials / per_col));     // a few rows per block
         FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_subtract_gradient_max<S>, dim3(per_col, gy), dim3(256), 0, s, (S*)u, (S*)v,
-                                                (const S*)p, pitch, n, row_lo, row_hi, h, partials));
+                                                (const S*)p, pitch, n, row_lo, row_hi, h, partials, pinv));
         hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(256), 0, s, partials, (int)(per_col * gy), max_out);
         return;
     }
     FLUID_BY_STORAGE(st, hipLaunchKernelGGL(k_subtract_gradient<S>, dim3(cdiv(n, 256), row_hi - row_lo), dim3(256), 0, s,
-                                            (S*)u, (S*)v, (const S*)p, pitch, n, row_lo, row_hi, h));
+                                            (S*)u, (S*)v, (const S*)p, pitch, n, row_lo, row_hi, h, pinv));
 }
 
 void launch_gradient_advect(hipStream_t s, int st, void* u, void* v, const void* p, void* d, const void* d0, int pitch, int n,
-                            int row_lo, int row_hi, float h, float dt0, int b)
+                            int row_lo, int row_hi, float h, float dt0, int b, float pinv)
 {
     if (row_hi <= row_lo) return;
     const dim3 grid(cdiv(n, 1024), row_hi - row_lo);
     if (narrow_index(st, pitch, n))
         FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_gradient_advect<S, unsigned>), grid, dim3(256), 0, s, (S*)u, (S*)v, (const S*)p,
-                                                (S*)d, (const S*)d0, pitch, n, row_lo, row_hi, h, dt0, b));
+                                                (S*)d, (const S*)d0, pitch, n, row_lo, row_hi, h, dt0, b, pinv));
     else
         FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_gradient_advect<S, size_t>), grid, dim3(256), 0, s, (S*)u, (S*)v, (const S*)p,
-                                                (S*)d, (const S*)d0, pitch, n, row_lo, row_hi, h, dt0, b));
+                                                (S*)d, (const S*)d0, pitch, n, row_lo, row_hi, h, dt0, b, pinv));
 }
 
 void launch_absmax2(hipStream_t s, int st, const void* u, const void* v, int pitch, int n, int row_lo, int row_hi,

@@ -288,6 +288,7 @@ void wrote(fluid_ctx* c, int f, int reach)
     c->reach[f] = c->nranks > 1 ? reach : kEverywhere;
     c->pend[f] = false;                        // overwritten: whatever the old contents still owed is moot
     c->src_of[f] = 0;
+    c->fscale[f] = 1.0f;                       // (a writer that keeps a scale sets it again afterwards)
 }
 
 // `async`: the compute stream does not wait for the rows (call_exchange); the caller's next solve joins them (xchg_join)
@@ -336,8 +337,20 @@ void rows(const fluid_ctx* c, int reach, int* lo, int* hi)
 // reader settles it with the real kernel first (here), and a writer that replaces the field drops it.
 int settle_source(fluid_ctx* c, int f);
 
-int settle(fluid_ctx* c, int f)
+// a field kept scaled (fscale) goes back to plain values: every row of it, one multiplication by a power of two
+int unscale(fluid_ctx* c, int f)
 {
+    if (c->fscale[f] == 1.0f) return FLUID_OK;
+    const float inv = 1.0f / c->fscale[f];
+    c->fscale[f] = 1.0f;
+    if (c->zero[f]) return FLUID_OK;
+    fluid::launch_scale(c->stream, c->st, c->f[f], c->pitch, 0, c->n + 2, inv);
+    return FLUID_OK;
+}
+
+int settle(fluid_ctx* c, int f, bool keep_scale = false)
+{
+    if (!keep_scale) TRY(unscale(c, f));
     if (c->src_of[f]) return settle_source(c, f);
     if (!c->pend[f]) return FLUID_OK;
     const int reach = c->nranks > 1 ? std::min(c->reach[f], exchange_cap(c)) : 0;
@@ -378,10 +391,10 @@ int materialize_zero(fluid_ctx* c, int f)
     return FLUID_OK;
 }
 
-int materialize(fluid_ctx* c, int f)
+int materialize(fluid_ctx* c, int f, bool keep_scale = false)
 {
     TRY(materialize_zero(c, f));
-    return settle(c, f);
+    return settle(c, f, keep_scale);
 }
 
 int materialize(fluid_ctx* c, std::initializer_list<int> fs)
@@ -395,6 +408,7 @@ void mark_zero(fluid_ctx* c, int f)
     c->zero[f] = true;
     c->pend[f] = false;
     c->src_of[f] = 0;
+    c->fscale[f] = 1.0f;
     c->reach[f] = kEverywhere;
 }
 
@@ -666,6 +680,18 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
             if (sv[j].x == sv[k].x || sv[j].x == sv[k].x0 || sv[j].x0 == sv[k].x)
                 return fail(FLUID_E_INVALID, "diffuse: the solves of a batch must not share fields");
     }
+    // The solve is linear in (x, x0): a right-hand side kept scaled (fp16 storage: the divergence, project()) gives a
+    // solution with the same factor, provided the first guess carries it too (a guess that is zero by definition does)
+    float out_scale[3] = {1.0f, 1.0f, 1.0f};
+    for (int k = 0; k < count; ++k) {
+        const float sx = c->zero[sv[k].x] ? c->fscale[sv[k].x0] : c->fscale[sv[k].x];
+        if (sx != c->fscale[sv[k].x0] || c->src_of[sv[k].x0]) {
+            if (c->fscale[sv[k].x] != 1.0f || c->fscale[sv[k].x0] != 1.0f) TRY(xchg_join(c, keep_pending));
+            TRY(unscale(c, sv[k].x));
+            TRY(unscale(c, sv[k].x0));
+        }
+        out_scale[k] = c->fscale[sv[k].x0];
+    }
     if (iters == 0) {
         TRY(xchg_join(c, keep_pending));
         for (int k = 0; k < count; ++k) TRY(settle_source(c, sv[k].x0));    // (no launch to take a deferred source over)
@@ -781,8 +807,8 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
             const int v = c->variant == fluid::JACOBI_TB ? (small ? fluid::JACOBI_NAIVE : fluid::JACOBI_STREAM) : c->variant;
             if (!joined) TRY(xchg_join(c, keep_pending));
             joined = true;
-            for (int j = 0; j < count; ++j) TRY(materialize(c, cur[j]));      // single-sweep kernels read x
-            for (int j = 0; j < count; ++j) TRY(settle(c, sv[j].x0));         // ... and x0 as it is in memory
+            for (int j = 0; j < count; ++j) TRY(materialize(c, cur[j], /*keep_scale=*/true));      // single-sweep kernels read x
+            for (int j = 0; j < count; ++j) TRY(settle(c, sv[j].x0, /*keep_scale=*/true));         // ... and x0 as it is in memory
             for (int j = 0; j < count; ++j)
                 fluid::launch_jacobi(c->stream, c->st, v, c->f[cur[j]], c->f[sv[j].x0], c->f[nxt[j]], c->pitch, c->n, lo, hi,
                                      sv[j].alpha, sv[j].beta, sv[j].b);
@@ -934,6 +960,7 @@ int op_diffuse_batch(fluid_ctx* c, const Solve* sv, int count, int iters, int fi
             std::swap(c->pend_inc[sv[j].x], c->pend_inc[kScratch[j]]);
         }
         wrote(c, kScratch[j], 0);
+        c->fscale[sv[j].x] = out_scale[j];
     }
     return timing_end(c, stop, iters * count);
 }
@@ -1058,7 +1085,8 @@ int op_advect2(fluid_ctx* c, int ba, int da, int d0a, int bb, int db, int d0b, i
 // FluidSequential.c:143-158.  `want`: rows past the slab on which the caller
 // would like the divergence (so that the pressure solve that follows needs no
 // exchange of its own); u and v are brought in one row further than that.
-int op_divergence(fluid_ctx* c, int u, int v, int p, int div, int want = 0)
+// `pscale`: the divergence is stored multiplied by this power of two (project() with fp16 storage; 1 from the operator API)
+int op_divergence(fluid_ctx* c, int u, int v, int p, int div, int want = 0, float pscale = 1.0f)
 {
     if (p == u || p == v || div == u || div == v || p == div)
         return fail(FLUID_E_INVALID, "divergence: outputs must not alias inputs");
@@ -1074,9 +1102,10 @@ int op_divergence(fluid_ctx* c, int u, int v, int p, int div, int want = 0)
     // p = 0 everywhere (FluidSequential.c:153 + set_bnd(0,p)): marked, not written
     TIMED(c, FLUID_TIME_DIVERGENCE,
           fluid::launch_divergence(c->stream, c->st, c->f[u], c->f[v], c->f[p], c->f[div], c->pitch, c->n, lo, hi, h,
-                                   /*write_p=*/0));
+                                   /*write_p=*/0, pscale));
     c->zero[div] = false;
     wrote(c, div, reach);
+    c->fscale[div] = pscale;
     mark_zero(c, p);
     return FLUID_OK;
 }
@@ -1087,12 +1116,13 @@ int op_subtract_gradient(fluid_ctx* c, int u, int v, int p, bool with_max = fals
 {
     if (p == u || p == v || u == v) return fail(FLUID_E_INVALID, "subtract_gradient: fields must be distinct");
     const float h = 1.0f / (float)c->n;
-    TRY(materialize(c, {u, v, p}));
+    TRY(materialize(c, {u, v}));
+    TRY(materialize(c, p, /*keep_scale=*/true));           // a scaled pressure is divided back inside the kernel, exactly
     TRY(need(c, {p}, 1));
     with_max = with_max && c->nranks > 1 && c->d_partials;
     TIMED(c, FLUID_TIME_PROJECTION,
           fluid::launch_subtract_gradient(c->stream, c->st, c->f[u], c->f[v], c->f[p], c->pitch, c->n, c->own0, c->own1, h,
-                                          c->d_partials, with_max ? c->d_scalar : nullptr));
+                                          c->d_partials, with_max ? c->d_scalar : nullptr, 1.0f / c->fscale[p]));
     wrote(c, u, 0);
     wrote(c, v, 0);
     return FLUID_OK;
@@ -1108,11 +1138,12 @@ int op_gradient_advect(fluid_ctx* c, int u, int v, int p, int b, int d, int d0, 
         return fail(FLUID_E_INVALID, "advect: output must not alias an input");
     if (c->nranks != 1) return fail(FLUID_E_INVALID, "op_gradient_advect is a one-GPU operator");
     const float h = 1.0f / (float)c->n;
-    TRY(materialize(c, {u, v, p, d0}));
+    TRY(materialize(c, {u, v, d0}));
+    TRY(materialize(c, p, /*keep_scale=*/true));
     c->zero[d] = false;
     TIMED(c, FLUID_TIME_PROJECTION,
           fluid::launch_gradient_advect(c->stream, c->st, c->f[u], c->f[v], c->f[p], c->f[d], c->f[d0], c->pitch, c->n, c->own0,
-                                        c->own1, h, dt * (float)c->n, b));
+                                        c->own1, h, dt * (float)c->n, b, 1.0f / c->fscale[p]));
     wrote(c, u, 0);
     wrote(c, v, 0);
     wrote(c, d, 0);
@@ -1168,17 +1199,19 @@ int project(fluid_ctx* c, int u, int v, int p, int div, int iters, const AdvectA
         c->zero[div] = false;               // about to be overwritten entirely
         c->pend[div] = false;
         c->reach[div] = c->nranks > 1 ? reach : kEverywhere;   // what the first launch can form from (u, v); it records what it stored
-        const DivSource ds{u, v, -0.5f * (1.0f / (float)c->n)};
+        const DivSource ds{u, v, (-0.5f * (1.0f / (float)c->n)) * c->pscale};
+        c->fscale[div] = c->pscale;         // (what the first launch stores; the solve is linear: p comes out with the same factor)
         c->in_pressure_solve = true;
         const int rc = op_diffuse(c, 0, p, div, 1.0f, 4.0f, iters, /*final_reach=*/1, &ds);
         c->in_pressure_solve = false;
         TRY(rc);
         TRY(xchg_join(c));
         wrote(c, div, 0);
+        c->fscale[div] = c->pscale;
         if (then_advect) return op_gradient_advect(c, u, v, p, then_advect->b, then_advect->d, then_advect->d0, then_advect->dt);
         return op_subtract_gradient(c, u, v, p, with_max);
     }
-    TRY(op_divergence(c, u, v, p, div, std::min(iters, c->halo - 1)));
+    TRY(op_divergence(c, u, v, p, div, std::min(iters, c->halo - 1), c->pscale));
     c->in_pressure_solve = true;            // timing only: reported separately (fluid_timing::pressure_ms)
     const int rc_solve = op_diffuse(c, 0, p, div, 1.0f, 4.0f, iters, /*final_reach=*/1);
     c->in_pressure_solve = false;
@@ -1324,7 +1357,10 @@ int copy_rows(fluid_ctx* c, int field, float* host, const float* chost, int row_
 {
     if (row_lo < 0 || row_hi > c->w || row_lo > row_hi) return fail(FLUID_E_INVALID, "bad row range");
     if (row_lo == row_hi) return FLUID_OK;
-    TRY(materialize(c, field));
+    // a download of a field kept scaled (fp16 storage: pressure, divergence) divides on the host, in float: exact, where a
+    // pass over the fp16 field would round the plain values into fp16's subnormals again
+    const float host_scale = (!to_device && c->st != fluid::STORAGE_F32) ? 1.0f / c->fscale[field] : 1.0f;
+    TRY(materialize(c, field, /*keep_scale=*/host_scale != 1.0f));
     char* dev = static_cast<char*>(c->row(field, row_lo)) + (size_t)XOFF * c->esz;
     const size_t rows = (size_t)(row_hi - row_lo), w = (size_t)c->w;
     const size_t dp = (size_t)c->pitch * c->esz;
@@ -1351,7 +1387,7 @@ int copy_rows(fluid_ctx* c, int field, float* host, const float* chost, int row_
         HIP_TRY(hipMemcpy2DAsync(stage.data(), hp, dev, dp, hp, rows, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         float* dst = host + (size_t)row_lo * w;
-        for (size_t k = 0; k < rows * w; ++k) dst[k] = (float)stage[k];
+        for (size_t k = 0; k < rows * w; ++k) dst[k] = (float)stage[k] * host_scale;
     }
     return FLUID_OK;
 }
@@ -1424,6 +1460,15 @@ int fluid_create_ex(const fluid_config* cfg, fluid_ctx** out)
     c->esz = fluid::storage_bytes(c->st);
     c->field_bytes = c->field_floats * c->esz;
     c->variant = cfg->jacobi_variant;
+    for (float& f : c->fscale) f = 1.0f;
+    if (c->st == fluid::STORAGE_F16 && n >= 16) {
+        // 2^(floor(log2 N) - 2): h * pscale lies in (1/8, 1/4], so a scaled divergence is at most a quarter of the velocity
+        // differences it is formed from -- no fp16 overflow that the plain field would not have had 2^12 earlier -- and the
+        // pressure of ordinary velocities sits in fp16's normal range instead of its subnormals
+        int e = 0;
+        (void)std::frexp((float)n, &e);                 // n = m * 2^e, m in [0.5, 1): floor(log2 n) = e - 1
+        c->pscale = std::ldexp(1.0f, e - 3);
+    }
     c->rank = cfg->rank;
     c->nranks = P;
     const int base = n / P, rem = n % P;
@@ -1690,6 +1735,13 @@ int fluid_set_param(fluid_ctx* c, int key, int value)
     case FLUID_PARAM_FUSE_ADD_SOURCE:
         c->fuse_add_source = value != 0;
         return FLUID_OK;
+    case FLUID_PARAM_F16_PRESSURE_SCALE: {
+        for (int f = 0; f < FLUID_NFIELDS; ++f) TRY(unscale(c, f));
+        int e = 0;
+        (void)std::frexp((float)c->n, &e);
+        c->pscale = (value != 0 && c->st == fluid::STORAGE_F16 && c->n >= 16) ? std::ldexp(1.0f, e - 3) : 1.0f;
+        return FLUID_OK;
+    }
     case FLUID_PARAM_XCHG_OVERLAP:
         TRY(xchg_join(c));
         c->xchg_overlap = value != 0;
@@ -1778,7 +1830,8 @@ int fluid_exchange_now(fluid_ctx* c, int kind, const int* fields, int nfields, i
         return fail(FLUID_E_INVALID, "halo depth %d outside [1, %d] (the shortest slab)", depth, c->min_slab);
     for (int k = 0; k < nfields; ++k) {
         TRY(check_fields(c, {fields[k]}));
-        TRY(settle(c, fields[k]));             // the caller is about to look at the rows: no increment may stay pending
+        TRY(settle(c, fields[k], /*keep_scale=*/true));   // the caller is about to look at the rows: no increment may stay pending
+                                                          // (a scale stays: it is the same on every rank, and a download undoes it)
     }
     c->in_halo_exchange = true;
     const int rc = call_exchange(c, kind, fields, nfields, depth, nullptr);

@@ -98,6 +98,11 @@ enum {
                                       waited for at once: the solve's first launch runs the strips that need this slab's own
                                       rows only while the rows travel, and the strips next to the slab's edges behind the
                                       exchange's event.  0: exchanges in line on the context's stream.  Speed only.   */
+    ,FLUID_PARAM_F16_PRESSURE_SCALE = 14 /* fp16 storage only.  1 (default): inside a step the divergence and the pressure of a
+                                      projection are stored multiplied by 2^(floor(log2 N) - 2) -- plain, they are of the order
+                                      h * |velocity| and fall into fp16's subnormal range from a few thousand cells per side
+                                      on -- and divided back exactly (in the gradient subtraction; on the host when u_prev /
+                                      v_prev are downloaded).  0: plain values.  Changes fp16 results (not fp32 ones).      */
     ,FLUID_PARAM_TB_MIN_CELLS = 4  /* FLUID_JACOBI_TB fuses sweeps only on slabs of at least this many cells
                                       (default 0: always); smaller ones run one-thread-per-cell sweeps   */
 };

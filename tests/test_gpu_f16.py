@@ -150,6 +150,35 @@ def test_full_step_stays_within_fp16_resolution_of_fp32(F, oracle):
         assert np.isfinite(got[k]).all() and err <= scale * 2.0 ** -8, "%s: err %.3g vs scale %.3g" % (k, err, scale)
 
 
+@pytest.mark.parametrize("n", [254, 1022, 2046, 4094])
+def test_scaled_pressure_keeps_the_projection_out_of_fp16_subnormals(F, oracle, n):
+    """Inside a step the divergence and the pressure of a projection are stored multiplied by 2^(floor(log2 N) - 2) (their
+    plain values are of the order h * |u|: fp16 subnormals from a few thousand cells per side on) and divided back exactly --
+    in the gradient subtraction, and on the host when u_prev / v_prev are downloaded.  One sourced step against the fp32
+    oracle, with the scale and without (FLUID_PARAM_F16_PRESSURE_SCALE): the scaled run must be at least as close.  How
+    close: the pressure is a smooth potential and the projection subtracts its GRADIENT, a small difference of neighbouring
+    values that carry 11 bits each, so the velocities' error grows with the grid -- measured 1.1e-3 of their magnitude at
+    256^2, 3e-3 at 2048^2, 8e-3 at 4096^2 (3.3e-2 at 16384^2, test_gpu_large.py) -- and the bound asserted is 2^-9 + 4e-6 N.
+    The numbers are printed (run with -s)."""
+    from fluidsimulationcuda_amd import capi
+    dens, dens0, u, u0, v, v0 = oracle.initialize_portable(n, seed=11)
+    got = {}
+    for scaled in (1, 0):
+        with solver(F, n, params={capi.PARAM_F16_PRESSURE_SCALE: scaled}) as s:
+            s.upload(u=u, v=v, dens=dens, u_prev=u0, v_prev=v0, dens_prev=dens0)
+            s.step(1, use_sources=True)
+            got[scaled] = {k: s.download(k) for k in ("u", "v", "dens", "u_prev", "v_prev")}
+    oracle.step_src(u, v, dens, u0, v0, dens0)
+    for k, want in (("u", u), ("v", v), ("dens", dens), ("u_prev", u0), ("v_prev", v0)):
+        scale = np.abs(want).max()
+        err = {m: float(np.abs(got[m][k] - want).max()) / scale for m in (1, 0)}
+        print("n=%d %-6s max|field| %.3g: err/scale with the scale %.3g, without %.3g" % (n, k, scale, err[1], err[0]))
+        assert np.isfinite(got[1][k]).all()
+        if k in ("u", "v", "dens"):
+            assert err[1] <= 2.0 ** -9 + 4e-6 * n, "%s at n=%d: %.3g of the field's magnitude" % (k, n, err[1])
+            assert err[1] <= err[0] * 1.25 + 2.0 ** -12
+
+
 def test_batched_and_unbatched_solves_agree(F):
     """fluid_step batches u/v/density diffusion into one launch; vel_step +
     dens_step called separately do not.  Same launches per field => same bits."""

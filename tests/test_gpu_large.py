@@ -129,11 +129,14 @@ def test_fp16_storage_against_fp32_at_16384(F):
     from oracle.oracle import Oracle
     from fluidsimulationcuda_amd import capi
     n = 16382
-    # what holds at this size (measured; see the report): the pressure of a 16384^2 projection is of the order h * |u| ~ 1e-5,
-    # i.e. inside fp16's SUBNORMAL range (quantum 6e-8), so the projected velocities are off by a few per cent of their
-    # magnitude after one step -- not the 2^-8 that holds at 256^2 (tests/test_gpu_f16.py) -- and the density, advected
-    # ~150 cells along them, by a few cells at its front (where an error of a few cells is an error of the field's size)
-    BOUND = {"u": 2.0 ** -3, "v": 2.0 ** -3, "dens": 2.0 ** -1}
+    # Bounds (of each fp32 field's largest magnitude; measured values in the report): velocities 2^-9 + 4e-6 N = 6.7e-2 -- the
+    # projection subtracts the GRADIENT of a smooth pressure, a small difference of neighbouring fp16 values, so its error grows
+    # with the grid (measured 3.3e-2 at a few cells, 1.5e-3 rms); the density, advected ~150 cells along those velocities,
+    # is off by a cell or two at its sharp front -- up to 0.2 of its magnitude there, 2e-3 rms (asserted: rms <= 2^-6).
+    # From the third step of the reference's decaying loop on the velocities themselves (5e-7) are fp16 subnormals: the
+    # floor of a few fp16 quanta (6e-8) applies.
+    BOUND = {"u": 2.0 ** -9 + 4e-6 * n, "v": 2.0 ** -9 + 4e-6 * n, "dens": 2.0 ** -1}
+    FLOOR = 8 * 2.0 ** -24
     dens, dens0, u, u0, v, v0 = Oracle().initialize_glibc(n, seed=1)
     report = {"n": n, "asserted_bound_of_scale": BOUND, "steps": []}
     with F.FluidSolver(n) as s32, F.FluidSolver(n, storage=capi.STORAGE_F16) as s16:
@@ -157,7 +160,8 @@ def test_fp16_storage_against_fp32_at_16384(F):
                 rms = float(np.sqrt(np.mean(np.square(a16, dtype=np.float64))))
                 row[k] = {"max_abs_fp32": scale, "max_abs_err": err, "err_over_scale": err / scale if scale else 0.0,
                           "rms_err_over_scale": rms / scale if scale else 0.0, "max_rel_err_cells_above_scale_2^-6": rel}
-                assert np.isfinite(err) and err <= scale * BOUND[k], "step %d %s: err %.3g vs scale %.3g" % (z, k, err, scale)
+                assert np.isfinite(err) and err <= max(scale * BOUND[k], FLOOR), "step %d %s: err %.3g vs scale %.3g" % (z, k, err, scale)
+                assert rms <= max(scale * 2.0 ** -6, FLOOR), "step %d %s: rms err %.3g vs scale %.3g" % (z, k, rms, scale)
             report["steps"].append(row)
         # how long until the fp16 velocities are exact zeros (fp32 keeps shrinking through its denormals much longer)
         flushed = None
