@@ -113,7 +113,7 @@ def test_timing_categories_count_every_operator():
     from fluidsimulationcuda_amd.harness import initialize_parameters, run_steps
     n = 254
     from fluidsimulationcuda_amd import capi
-    with F.FluidSolver(n, params={capi.PARAM_FUSE_DIVERGENCE: 0}) as s:     # every operator as a launch of its own
+    with F.FluidSolver(n, params={capi.PARAM_FUSE_DIVERGENCE: 0, capi.PARAM_FUSE_ADD_SOURCE: 0}) as s:     # every operator as a launch of its own
         s.upload(**initialize_parameters(n))
         s.timing_enable(True)
         s.step(1, use_sources=True)
@@ -137,6 +137,7 @@ def test_timing_categories_count_every_operator():
         s.step(2)
         t = s.timing_read()
         assert (t["divergence_calls"], t["solves"], t["sweeps"], t["projection_calls"]) == (0, 9, 600, 6)
+        assert t["source_calls"] == 0      # ... and the sources are added by the first launch of the diffusion that consumes the sums
 
 
 @pytest.mark.gpu
