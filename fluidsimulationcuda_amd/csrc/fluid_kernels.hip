@@ -1260,6 +1260,15 @@ __device__ __forceinline__ void wave_cells_out(S* __restrict__ p, int cells, flo
     }
 }
 
+// (Round 3 built the version DESIGN.md had sketched -- the taps staged in LDS: a block takes a tile of 8 or 16 rows x 256
+// columns, computes all its back-traces, reduces their bounding box, loads the box with coalesced 16-byte accesses when it
+// fits 12-24 rows x 272 columns per field and reads every tap from LDS, else gathers as here.  Bit-identical, 1.6 instead of 5
+// vector-memory instructions per cell -- and slower wherever the back-traces are short or smooth, which is the workload:
+// 8192^2, one field, smooth velocity: 196-210 us against 178-196 here (16-row tiles: 243-264); two fields inside a step: 329 us
+// against 275 (decaying data), 546 against 555 (ordinary data).  It only won on large AND noisy velocities (13-cell
+// back-traces of white noise: 366 against 490 us).  Two block-wide barriers, the staging burst and 34-60 KB of LDS per block
+// (2-4 blocks per CU) cost more than the gathers they replace; the single-field kernel here already moves its 1074 MB at
+// 6.0 TB/s.  Not kept.)
 // (A block that walks eight rows and loads the next row's velocity ahead of the current row's taps was measured slower:
 // 324 against 294 us at 8192^2.  The texture addresser is busy 94 % of k_advect2's time -- rocprofv3 TA_BUSY_avr --
 // so what these kernels wait for is the address path of their gathers, neither HBM nor latency.)
@@ -1331,143 +1340,6 @@ __global__ __launch_bounds__(256) void k_advect2(S* __restrict__ da, const S* __
             if (j <= n) {
                 emit_ghosts(da, (size_t)pitch, n, ba, j, i, va[k]);
                 emit_ghosts(db, (size_t)pitch, n, bb, j, i, vb[k]);
-            }
-        }
-    }
-}
-
-// The advections with their taps staged in LDS (round 3).  A block takes a tile of TH rows x 256 columns (each of its four
-// waves TH/4 rows; within a row the wave's 256 cells as above: own cells in and out as one 16-byte access per lane, turned
-// into lane-contiguous order through a wave-private LDS tile).  All back-traces of the tile are computed first and the block
-// reduces their bounding box; if the box -- columns rounded out to 16-byte boundaries, plus the row and the column the
-// bilinear taps reach into -- fits the staging area (kStageRows x kStageCols floats per advected field), the block loads it
-// with coalesced 16-byte accesses and every tap is an LDS read; else (a tile whose velocities scatter its back-traces over
-// more rows or columns than that: the walls' clamps, a shear layer) the taps are gathered from memory as before.  The box is
-// found from the data, so the velocity may be as large as it likes -- a tile of ordinary, smooth velocity lands in a window
-// of about its own size, wherever that window lies.  What this buys is vector-memory instructions, which is what these
-// kernels wait for (the texture addresser: ~21 cycles per instruction and CU): per cell 0.25 x 2 velocity loads + 0.25 x NF
-// stores + ~0.4 x NF staging loads instead of + 2 x NF gathers.  Arithmetic and its order are untouched.
-constexpr int kStageCols = 272, kStageRowsExtra = 8;
-
-template <int NF, int TH, typename S>
-__global__ __launch_bounds__(256) void k_advect_lds(S* __restrict__ da, const S* __restrict__ d0a, int ba, S* __restrict__ db,
-                                                    const S* __restrict__ d0b, int bb, const S* __restrict__ u,
-                                                    const S* __restrict__ v, int pitch, int n, int row_lo, int row_hi, float dt0)
-{
-    constexpr int RW = TH / 4;                           // rows per wave
-    constexpr int LR = TH + kStageRowsExtra;
-    __shared__ __attribute__((aligned(16))) float stage[NF][LR][kStageCols];
-    __shared__ __attribute__((aligned(16))) float xch[4][2][256];
-    __shared__ int red[4][4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c0 = 1 + (int)blockIdx.x * 256;            // the tile's first column
-    const int cells = min(256, n + 1 - c0);              // how many of its 256 columns exist (>= 1 by the grid's size)
-    const int i_first = row_lo + (int)blockIdx.y * TH + wave * RW;
-    const unsigned E = (unsigned)sizeof(S), P = (unsigned)pitch * E;
-    // 1. this wave's velocities and back-traces (FluidSequential.c:111-134), kept as tap cell + weights
-    int tj[RW][kAdvectRounds], ti[RW][kAdvectRounds];
-    float s1[RW][kAdvectRounds], t1[RW][kAdvectRounds];
-    int jmin = 0x7fffffff, jmax = -1, imin = 0x7fffffff, imax = -1;
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        const int i = i_first + r;
-        if (i >= row_hi) break;                          // wave-uniform
-        const unsigned row = (unsigned)i * P + (unsigned)(XOFF + c0) * E;
-        float uu[kAdvectRounds], vv[kAdvectRounds];
-        wave_cells_in(at(u, row), cells, xch[wave][0], uu);
-        wave_cells_in(at(v, row), cells, xch[wave][1], vv);
-#pragma unroll
-        for (int k = 0; k < kAdvectRounds; ++k) {
-            const int j = min(c0 + lane + 64 * k, n);
-            float px = (float)j - dt0 * uu[k];
-            float py = (float)i - dt0 * vv[k];
-            const float hi = (float)n + 0.5f;
-            px = __builtin_fminf(__builtin_fmaxf(px, 0.5f), hi);
-            py = __builtin_fminf(__builtin_fmaxf(py, 0.5f), hi);
-            const int j0 = (int)px, i0 = (int)py;
-            tj[r][k] = j0;
-            ti[r][k] = i0;
-            s1[r][k] = px - (float)j0;
-            t1[r][k] = py - (float)i0;
-            jmin = min(jmin, j0); jmax = max(jmax, j0);
-            imin = min(imin, i0); imax = max(imax, i0);
-        }
-    }
-    // 2. the tile's bounding box
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        jmin = min(jmin, __shfl_xor(jmin, off, 64)); jmax = max(jmax, __shfl_xor(jmax, off, 64));
-        imin = min(imin, __shfl_xor(imin, off, 64)); imax = max(imax, __shfl_xor(imax, off, 64));
-    }
-    if (lane == 0) { red[wave][0] = jmin; red[wave][1] = jmax; red[wave][2] = imin; red[wave][3] = imax; }
-    __syncthreads();
-    jmin = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
-    jmax = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
-    imin = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
-    imax = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
-    // columns from the 16-byte boundary at or below jmin (column c sits at element c + XOFF, XOFF % 4 == 3: c % 4 == 1) up to
-    // jmax + 1; rows imin .. imax + 1.  A wave without rows (a ragged last tile) contributes nothing; a block without any
-    // row does not exist (the grid covers [row_lo, row_hi)).
-    const int jlo = jmin - ((jmin + 3) & 3);
-    const int w4 = (jmax + 1 - jlo) / 4 + 1;             // 4-float groups per staged row
-    const int nrows = imax + 1 - imin + 1;
-    const bool staged = jmax >= 0 && w4 * 4 <= kStageCols && nrows <= LR;        // block-uniform
-    if (staged) {
-        // 3. the box, both fields, as aligned 16-byte loads; groups past the row's last one repeat it (their floats are unused)
-        const int last4 = (pitch - (XOFF + jlo)) / 4 - 1;
-        const S* src[2] = {d0a, d0b};
-        for (int idx = threadIdx.x; idx < nrows * (kStageCols / 4); idx += 256) {
-            const int r = idx / (kStageCols / 4), q = idx % (kStageCols / 4);
-            if (q >= w4) continue;
-            const unsigned o = (unsigned)(imin + r) * P + (unsigned)(XOFF + jlo + 4 * min(q, last4)) * E;
-#pragma unroll
-            for (int f = 0; f < NF; ++f) *reinterpret_cast<float4*>(&stage[f][r][4 * q]) = ld4(at(src[f], o));
-        }
-    }
-    __syncthreads();
-    // 4. the taps and the interpolation (FluidSequential.c:136-137), results out, ghost cells where the tile touches a wall
-    const bool wall_cols = blockIdx.x == 0 || blockIdx.x == gridDim.x - 1;
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        const int i = i_first + r;
-        if (i >= row_hi) break;
-        float va[kAdvectRounds], vb[kAdvectRounds];
-#pragma unroll
-        for (int k = 0; k < kAdvectRounds; ++k) {
-            const float a1 = s1[r][k], a0 = 1.0f - a1, b1 = t1[r][k], b0 = 1.0f - b1;
-            float q00, q10, q01, q11;
-            if (staged) {
-                const float* t = &stage[0][ti[r][k] - imin][tj[r][k] - jlo];
-                q00 = t[0]; q10 = t[1]; q01 = t[kStageCols]; q11 = t[kStageCols + 1];
-            } else {
-                const unsigned o = (unsigned)ti[r][k] * P + (unsigned)(XOFF + tj[r][k]) * E;
-                ld_pair(at(d0a, o), q00, q10);
-                ld_pair(at(d0a, o + P), q01, q11);
-            }
-            va[k] = a0 * (b0 * q00 + b1 * q01) + a1 * (b0 * q10 + b1 * q11);
-            if (NF == 2) {
-                if (staged) {
-                    const float* t = &stage[NF - 1][ti[r][k] - imin][tj[r][k] - jlo];
-                    q00 = t[0]; q10 = t[1]; q01 = t[kStageCols]; q11 = t[kStageCols + 1];
-                } else {
-                    const unsigned o = (unsigned)ti[r][k] * P + (unsigned)(XOFF + tj[r][k]) * E;
-                    ld_pair(at(d0b, o), q00, q10);
-                    ld_pair(at(d0b, o + P), q01, q11);
-                }
-                vb[k] = a0 * (b0 * q00 + b1 * q01) + a1 * (b0 * q10 + b1 * q11);
-            }
-        }
-        const unsigned row = (unsigned)i * P + (unsigned)(XOFF + c0) * E;
-        wave_cells_out(at(da, row), cells, xch[wave][0], va);
-        if (NF == 2) wave_cells_out(at(db, row), cells, xch[wave][1], vb);
-        if (wall_cols || i == 1 || i == n) {
-#pragma unroll
-            for (int k = 0; k < kAdvectRounds; ++k) {
-                const int j = c0 + lane + 64 * k;
-                if (j <= n) {
-                    emit_ghosts(da, (size_t)pitch, n, ba, j, i, va[k]);
-                    if (NF == 2) emit_ghosts(db, (size_t)pitch, n, bb, j, i, vb[k]);
-                }
             }
         }
     }
@@ -1694,12 +1566,7 @@ __global__ __launch_bounds__(256) void k_residual(const S* __restrict__ x, const
 // `st` selects the field storage type the untyped pointers refer to.
 // ---------------------------------------------------------------------------
 static inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
-// the advections stage their taps in LDS (k_advect_lds) unless FLUID_ADVECT_LDS=0 is in the environment (A/B timing aid)
-static inline bool advect_taps_in_lds()
-{
-    static const bool on = [] { const char* e = std::getenv("FLUID_ADVECT_LDS"); return !(e && e[0] == '0'); }();
-    return on;
-}
+
 // element offsets into a field fit 32 bits (with a byte offset below 2^32 for the hardware's address add)
 static inline bool narrow_index(int st, int pitch, int n) { return (size_t)(n + 2) * (size_t)pitch * storage_bytes(st) < (1ull << 32); }
 
@@ -1884,12 +1751,7 @@ void launch_advect(hipStream_t s, int st, void* d, const void* d0, const void* u
 {
     if (row_hi <= row_lo) return;
     const dim3 grid(cdiv(n, 1024), row_hi - row_lo);
-    if (narrow_index(st, pitch, n) && advect_taps_in_lds()) {
-        constexpr int TH = 16;
-        const dim3 tiles(cdiv(n, 256), cdiv(row_hi - row_lo, TH));
-        FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_advect_lds<1, TH, S>), tiles, dim3(256), 0, s, (S*)d, (const S*)d0, b, (S*)d,
-                                                (const S*)d0, b, (const S*)u, (const S*)v, pitch, n, row_lo, row_hi, dt0));
-    } else if (narrow_index(st, pitch, n))
+    if (narrow_index(st, pitch, n))
         FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_advect<S, unsigned>), grid, dim3(256), 0, s, (S*)d, (const S*)d0, (const S*)u,
                                                 (const S*)v, pitch, n, row_lo, row_hi, dt0, b));
     else
@@ -1902,12 +1764,7 @@ void launch_advect2(hipStream_t s, int st, void* da, const void* d0a, int ba, vo
 {
     if (row_hi <= row_lo) return;
     const dim3 grid(cdiv(n, 1024), row_hi - row_lo);
-    if (narrow_index(st, pitch, n) && advect_taps_in_lds()) {
-        constexpr int TH = 16;
-        const dim3 tiles(cdiv(n, 256), cdiv(row_hi - row_lo, TH));
-        FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_advect_lds<2, TH, S>), tiles, dim3(256), 0, s, (S*)da, (const S*)d0a, ba, (S*)db,
-                                                (const S*)d0b, bb, (const S*)u, (const S*)v, pitch, n, row_lo, row_hi, dt0));
-    } else if (narrow_index(st, pitch, n))
+    if (narrow_index(st, pitch, n))
         FLUID_BY_STORAGE(st, hipLaunchKernelGGL((k_advect2<S, unsigned>), grid, dim3(256), 0, s, (S*)da, (const S*)d0a, ba, (S*)db,
                                                 (const S*)d0b, bb, (const S*)u, (const S*)v, pitch, n, row_lo, row_hi, dt0));
     else
