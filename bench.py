@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--no-scaling-base", action="store_true", help="skip the other side of the speed-up (N=1: the 8192^2 run; "
                                                                    "N>1: rank 0's single-GPU runs)")
     ap.add_argument("--no-second-grid", action="store_true", help="N>1: skip the 4096^2 leg")
+    ap.add_argument("--overlap", type=int, default=-1, choices=[-1, 0, 1],
+                    help="N>1: FLUID_PARAM_XCHG_OVERLAP (halo exchange beside the interior strips of the solve it feeds): 1 on, 0 off, "
+                         "-1 (default) a few untimed steps each way on every grid, the faster one kept for the timed steps")
     ap.add_argument("--no-ordinary", action="store_true", help="skip the value_ordinary_data leg")
     ap.add_argument("--only-ordinary", action="store_true", help="profiling aid: run only the ordinary-data leg")
     ap.add_argument("--seed", type=int, default=1)
@@ -322,17 +325,21 @@ def main():
             s.set_param(3, a.fast_division)
         if a.t16_min_cells >= 0:
             s.set_param(7, a.t16_min_cells)
+        if world > 1 and overlap_choice.get(n_) is not None:
+            s.set_param(13, overlap_choice[n_])
         return s
 
     tuning = {}
     native = [False]
+    overlap_choice = {}          # grid size n -> FLUID_PARAM_XCHG_OVERLAP for this job's contexts (None: the library's default)
+    overlap_trials = {}
 
     def tune(n_):
         """The library measures the fused kernel's strip heights during the first launches of each launch shape
         (FLUID_PARAM_TB_AUTOTUNE) and keeps the result for the process: let it finish in a throw-away context so that
         neither the warm-up nor the timed steps contain trial launches.  Not counted as steps; the same number of
         steps on every rank (a step holds collectives)."""
-        if a.variant != 3 or a.tb_rows or (n_, world) in tuning:
+        if a.variant != 3 or a.tb_rows or (n_, world, overlap_choice.get(n_)) in tuning:
             return
         s = make(n_)
         s.set_param(12, 0)      # FUSE_ADD_SOURCE off here: the sourced step's own launch shape is tune_ordinary()'s business
@@ -347,10 +354,34 @@ def main():
             s.synchronize()
             if world == 1 and s.autotune_pending() == 0:
                 break
-        tuning[(n_, world)] = {"untimed_steps": steps, "shapes_still_open": s.autotune_pending()}
+        tuning[(n_, world, overlap_choice.get(n_))] = tuning[(n_, world)] = {"untimed_steps": steps, "shapes_still_open": s.autotune_pending()}
         s.close()
 
+    def choose_overlap(n_):
+        """Row slabs: whether the halo exchange that feeds a solve runs beside that solve's interior strips (one more, small,
+        launch and two stream hops per solve; pays when the exchange takes longer than those) is a speed-only switch whose
+        verdict depends on the fabric -- so it is measured: a few untimed steps each way (tuner settled for each), max over ranks,
+        the faster one kept for this grid's timed steps.  Results are identical either way."""
+        if world == 1 or n_ in overlap_choice:
+            return
+        if a.overlap >= 0:
+            overlap_choice[n_] = a.overlap
+            return
+        ms = {}
+        for ov in (1, 0):
+            overlap_choice[n_] = ov
+            tune(n_)
+            s = make(n_)
+            s.load_global(**initialize_parameters(n_, seed=a.seed))
+            e, _j, _p, _t = measure(s, dist, world, 4, 2, a.iters)
+            s.close()
+            ms[ov] = e * 1e3 / 4
+        overlap_choice[n_] = 1 if ms[1] <= ms[0] else 0
+        overlap_trials[n_] = {"overlap_ms_per_step": ms[1], "in_line_ms_per_step": ms[0], "chosen": overlap_choice[n_],
+                              "note": "FLUID_PARAM_XCHG_OVERLAP measured both ways over 4 untimed steps before the warm-up"}
+
     def run(n_, steps, warmup, fuse_divergence=True):
+        choose_overlap(n_)
         tune(n_)
         fields = initialize_parameters(n_, seed=a.seed)     # same seed on every rank
         s = make(n_, fuse_divergence)
@@ -526,6 +557,7 @@ def main():
                                          "per_step": {"halo": calls[0] / (steps + warmup), "max": calls[2] / (steps + warmup)}}
         if world > 1:
             out["native_exchange"] = bool(native[0])
+            out["exchange_overlap"] = overlap_trials.get(n_, {"chosen": overlap_choice.get(n_), "note": "--overlap given"})
         return out, fields, (elapsed, jac_ms, prs_ms, t)
 
     def single_gpu(grid_, steps, warmup):

@@ -65,6 +65,8 @@ def test_bench_gpus_2_as_typed_starts_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["grid"] == 512 and d["native_exchange"] is False
+    ov = d["exchange_overlap"]                             # measured both ways before the warm-up, the faster kept
+    assert ov["chosen"] in (0, 1) and ov["overlap_ms_per_step"] > 0 and ov["in_line_ms_per_step"] > 0
     assert 0 < d["roofline"]["frac_compulsory"] < 1
     g = d["grid_4096"]
     assert g["value"] > 0 and g["ms_per_step"] > 0 and 0 < g["roofline"]["frac_compulsory"] < 1
