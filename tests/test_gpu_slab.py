@@ -322,6 +322,27 @@ def test_two_term_division_on_slabs_with_tiny_values_in_the_neighbours_rows(orac
     assert_bit_equal(got["u"], want, "two-term division on slabs, halo %d" % halo)
 
 
+def test_halo_depth_is_checked_against_the_shortest_slab_on_every_rank():
+    """N = 257 over 3 slabs: 86, 86 and 85 rows.  A halo of 86 rows fits the tall slabs and not the short one; checked
+    against each rank's own height, the tall ranks would enter the exchange and wait for a peer that has already
+    returned an error.  fluid_exchange_now validates against the shortest slab, which every rank knows: all three refuse,
+    none calls its exchange; 85 rows pass on all three."""
+    import ctypes as C
+    from fluidsimulationcuda_amd import capi
+    n, nranks = 257, 3
+    rcs = {}
+
+    def body(s):
+        ids = (C.c_int * 1)(capi.U)
+        rcs[s.rank] = (capi.lib().fluid_exchange_now(s._h, capi.XCHG_HALO, ids, 1, 86),
+                       capi.lib().fluid_exchange_now(s._h, capi.XCHG_HALO, ids, 1, 85))
+
+    _, fab = run_ranks(n, nranks, 0, synthetic(n), body, jacobi=3)
+    assert all(rcs[r] == (capi.E_INVALID, capi.OK) for r in range(nranks)), rcs
+    for r in range(nranks):
+        assert [e for e in fab.log[r] if e[0] == capi.XCHG_HALO] == [(capi.XCHG_HALO, (capi.U,), 85)]
+
+
 def test_too_many_slabs_is_rejected():
     from fluidsimulationcuda_amd import capi
     from fluidsimulationcuda_amd.solver import FluidSolver
