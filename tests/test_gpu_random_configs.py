@@ -1,7 +1,8 @@
 """GPU: seeded random configurations.  The hand-picked cases elsewhere fix most knobs at a time; here they vary
 together -- grid size, sweep count, launch depth, lanes, strip height, division form, the fused divergence, the tuner --
-so that interactions between the round-2 paths (planned depths, 12-sweep launches, divergence inside the pressure solve,
-second stream on slabs) are exercised.  One GPU: two steps against the oracle, all six fields.  Slabs (in-process
+so that interactions between the round-2 and round-3 paths (planned depths, 12-sweep launches, divergence inside the pressure
+solve, second stream on slabs; the scaled-residual division, add_source inside the first diffusion launch, launches split around
+an exchange in flight) are exercised.  One GPU: two steps against the oracle, all six fields.  Slabs (in-process
 fabric): two steps against one context, plus the requirement that every rank issues the same exchange sequence."""
 import os
 
@@ -24,6 +25,7 @@ def random_params(rng, capi):
          capi.PARAM_TB_ROWS: int(rng.choice([0, 0, 1, 2, 5, 17, 64, 1000])),
          capi.PARAM_TB_FAST_DIVISION: int(rng.choice([0, 1, 2, 2, 3])),
          capi.PARAM_FUSE_DIVERGENCE: int(rng.choice([0, 1, 1])),
+         capi.PARAM_FUSE_ADD_SOURCE: int(rng.choice([0, 1, 1])),
          capi.PARAM_TB_AUTOTUNE: int(rng.choice([0, 1])),
          capi.PARAM_TB_EDGE_ROWS_PCT: int(rng.choice([40, 0, 100]))}
     return p
@@ -70,6 +72,7 @@ def test_random_slab_configuration_matches_one_context(seed):
     jacobi = int(rng.choice([3, 3, 3, 0]))
     params = random_params(rng, capi)
     params[capi.PARAM_SLAB_OVERLAP] = int(rng.choice([0, 1, 1]))
+    params[capi.PARAM_XCHG_OVERLAP] = int(rng.choice([0, 1, 1]))
     params.pop(capi.PARAM_TB_MIN_CELLS)          # (the fake ranks force it to 0, as the single-context reference does)
     if storage == 1:
         # fp16 results depend on the launch schedule: keep the knobs that change it at their defaults on both sides
