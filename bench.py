@@ -649,6 +649,12 @@ def main():
                                 "roofline_frac": BYTES_PER_CELL_SWEEP * 8192 * 8192 / r2["t_sweep"] / 1e9 / HBM_PEAK_GBS,
                                 "frac_compulsory": BYTES_PER_CELL_SWEEP * 8192 * 8192 * t2["jacobi_field_launches"]
                                 / (j2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if not a.no_ordinary:
+            eo, jo, po, to, copy_o, solve_o = run_ordinary(8190, steps2, 2)
+            ro = rates(eo, jo, po, to, steps2, 8192 * 8192, solve_o)
+            line["scaling_base"]["ordinary_data"] = {"ms_per_step": ro["ms_per_step"], "value": ro["value"],
+                                                     "all_solves_value": ro["all_solves_value"],
+                                                     "source_copies_ms_per_step": copy_o}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(n, fields, a.iters)
     if rank == 0:
