@@ -10,7 +10,7 @@ rows have to move and calls back; this module only moves them, with
 torch.distributed point-to-point ops (backend "nccl" = RCCL over xGMI on the
 GPU box, "gloo" in the CPU tests) on torch tensors that alias the context's
 device arena.  Every rank keeps full-size fields (288 GB of HBM per GPU makes
-that free: 9 fields x 256 MiB at 8192^2), computes only its slab, and global row
+that free: 12 fields x 260 MiB at 8192^2), computes only its slab, and global row
 r is local row r -- so a halo is just rows [own-depth, own) and the advect
 fallback is an in-place all-gather.
 """
